@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python code.
+
+Runs only in the build container (needs /root/reference; read-only import,
+nothing is copied).  It
+  1. imports the reference DINOv2 (`dinov2.dinov2.models.vision_transformer`)
+     and the reference `CoarseMatching` (loaded by file path — the file needs
+     only torch + einops),
+  2. loads seeded synthetic weights (pope_amd.synth.synthetic_state_dict; the
+     real checkpoints are not available offline),
+  3. checks the CPU restatement in oracle/ against the reference outputs, and
+  4. writes the reference outputs as small fixtures.
+
+Usage:  python oracle/gen_golden.py            (from the repo root)
+"""
+import importlib.util
+import logging
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(1, REF)
+logging.disable(logging.WARNING)
+
+from oracle import coarse_match_ref as cm_ref  # noqa: E402
+from oracle import dinov2_ref  # noqa: E402
+from pope_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(8)
+
+
+def load_reference_vit(sd):
+    from dinov2.dinov2.models import vision_transformer as vits
+    # == load_dinov2_model() (dinov2_utils.py:38-47) minus the config/weights files
+    m = vits.vit_small(patch_size=14, img_size=518, init_values=1e-5, ffn_layer="mlp",
+                       block_chunks=0, qkv_bias=True, proj_bias=True, ffn_bias=True)
+    m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+def load_reference_coarse_matching():
+    spec = importlib.util.spec_from_file_location(
+        "ref_coarse_matching", os.path.join(REF, "src/matcher/utils/coarse_matching.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg = {"thr": 0.2, "border_rm": 2, "match_type": "dual_softmax", "dsmax_temperature": 0.1,
+           "train_coarse_percent": 0.4, "train_pad_num_gt_min": 200}  # cvpr_ds_config.py:30-40
+    return mod.CoarseMatching(cfg).eval()
+
+
+def sd_digest(sd):
+    return np.array([float(sd[k].double().sum()) for k in sorted(sd)], np.float64)
+
+
+def maxdiff(a, b):
+    return float((a - b).abs().max())
+
+
+def run_ref_vit(model, x):
+    taps = {}
+    hooks = []
+    for i in (0, 5, 11):
+        blk = model.blocks[i]
+        hooks.append(blk.attn.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(f"attn{i}", o.detach())))
+        hooks.append(blk.mlp.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(f"mlp{i}", o.detach())))
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(f"blk{i}", o.detach())))
+    with torch.no_grad():
+        out = model(x, is_training=True)
+        tokens = model.prepare_tokens_with_masks(x)
+    for h in hooks:
+        h.remove()
+    taps["tokens"] = tokens
+    return out, taps
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    sd = synth.synthetic_state_dict(seed=0)
+    assert len(sd) == 175
+    model = load_reference_vit(sd)
+    cmatch = load_reference_coarse_matching()
+    digest = sd_digest(sd)
+
+    # ---------------- DINOv2 forward ----------------
+    for name, (B, H, W, stride) in {"vit_196": (2, 196, 196, 3), "vit_224": (2, 224, 224, 4),
+                                    "vit_476x630": (1, 476, 630, 12)}.items():
+        x = synth.synthetic_images(B, H, W, seed=11)
+        out, taps = run_ref_vit(model, x)
+        o_taps = {}
+        mine = dinov2_ref.forward_features(sd, x, taps=o_taps)
+        d = {k: maxdiff(out[k], mine[k]) for k in ("x_norm_clstoken", "x_norm_patchtokens", "x_prenorm")}
+        d["tokens"] = maxdiff(taps["tokens"], o_taps["tokens"])
+        for i in (0, 5, 11):
+            d[f"attn{i}"] = maxdiff(taps[f"attn{i}"], o_taps[i]["attn_branch"])
+            d[f"mlp{i}"] = maxdiff(taps[f"mlp{i}"], o_taps[i]["mlp_branch"])
+            d[f"blk{i}"] = maxdiff(taps[f"blk{i}"], o_taps[i]["x_out"])
+        print(name, "oracle-vs-reference max abs diff:", {k: f"{v:.2e}" for k, v in d.items()})
+        assert max(d.values()) <= 1e-5, d
+        xn = torch.cat([out["x_norm_clstoken"][:, None], out["x_norm_patchtokens"]], 1)
+        rows = torch.arange(0, xn.shape[1], stride)
+        fx = {
+            "weights_seed": 0, "weights_digest": digest, "input_seed": 11, "shape": np.array([B, H, W]),
+            "input_digest": np.array([float(x.double().sum()), float(x.double().abs().sum())]),
+            "rows": rows.numpy(),
+            "x_norm": xn[:, rows].numpy(), "x_prenorm": out["x_prenorm"][:, rows].numpy(),
+            "tokens": taps["tokens"][:, rows].numpy(),
+            "cls": model(x).detach().numpy(),
+        }
+        for i in (0, 5, 11):
+            fx[f"attn{i}"] = taps[f"attn{i}"][:, rows].numpy()
+            fx[f"mlp{i}"] = taps[f"mlp{i}"][:, rows].numpy()
+            fx[f"blk{i}"] = taps[f"blk{i}"][:, rows].numpy()
+        np.savez(os.path.join(OUT, name + ".npz"), **fx)
+
+    # ---------------- dense matcher on DINOv2 patch tokens ----------------
+    for name, (H, W) in {"match_224": (224, 224), "match_476x630": (476, 630)}.items():
+        n_pairs = 2 if H == 224 else 1
+        i0, i1 = synth.synthetic_pairs(n_pairs, H, W, seed=5)
+        with torch.no_grad():
+            f0 = model(i0, is_training=True)["x_norm_patchtokens"]
+            f1 = model(i1, is_training=True)["x_norm_patchtokens"]
+        hw_c = (H // 14, W // 14)
+        data = {"hw0_i": (H, W), "hw1_i": (H, W), "hw0_c": hw_c, "hw1_c": hw_c}
+        with torch.no_grad():
+            cmatch(f0, f1, data)
+        mine = cm_ref.dense_match(f0, f1, hw_c, hw_c, (H, W))
+        assert torch.equal(mine["conf_matrix"], data["conf_matrix"])
+        for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_c", "mkpts1_c", "m_bids"):
+            assert torch.equal(mine[k], data[k]), k
+        conf = data["conf_matrix"]
+        print(name, "matches:", len(data["i_ids"]), "mconf range",
+              float(data["mconf"].min()), float(data["mconf"].max()))
+        assert len(data["i_ids"]) > 50
+        np.savez(os.path.join(OUT, name + ".npz"),
+                 weights_seed=0, weights_digest=digest, pair_seed=5, shape=np.array([n_pairs, H, W]),
+                 feat0_digest=np.array([float(f0.double().sum())]), feat1_digest=np.array([float(f1.double().sum())]),
+                 feat0_rows=f0[:, ::16].numpy(), feat1_rows=f1[:, ::16].numpy(),
+                 b_ids=data["b_ids"].numpy(), i_ids=data["i_ids"].numpy(), j_ids=data["j_ids"].numpy(),
+                 mconf=data["mconf"].numpy(), mkpts0_c=data["mkpts0_c"].numpy(), mkpts1_c=data["mkpts1_c"].numpy(),
+                 conf_rowmax=conf.max(2)[0].numpy(), conf_rowarg=conf.max(2)[1].numpy(),
+                 conf_colmax=conf.max(1)[0].numpy(), conf_colarg=conf.max(1)[1].numpy(),
+                 conf_sum=np.array([float(conf.double().sum())]))
+
+    # ---------------- dense matcher on LoFTR-shaped features (C=256) ----------------
+    g = torch.Generator().manual_seed(3)
+    n, hc, wc, C = 2, 16, 20, 256
+    L = hc * wc
+    f0 = torch.randn(n, L, C, generator=g) * 3.0
+    perm = torch.stack([torch.randperm(L, generator=g) for _ in range(n)])
+    f1 = torch.gather(f0, 1, perm[..., None].expand(-1, -1, C)) + 0.3 * torch.randn(n, L, C, generator=g)
+    # exact duplicates to exercise tie handling (first index wins)
+    f1[0, 77] = f1[0, 76]
+    f0[1, 101] = f0[1, 100]
+    data = {"hw0_i": (hc * 8, wc * 8), "hw1_i": (hc * 8, wc * 8), "hw0_c": (hc, wc), "hw1_c": (hc, wc)}
+    with torch.no_grad():
+        cmatch(f0, f1, data)
+    mine = cm_ref.dense_match(f0, f1, (hc, wc), (hc, wc), (hc * 8, wc * 8))
+    for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_c", "mkpts1_c"):
+        assert torch.equal(mine[k], data[k]), k
+    print("match_loftr256 matches:", len(data["i_ids"]))
+    assert len(data["i_ids"]) > 50
+    np.savez(os.path.join(OUT, "match_loftr256.npz"), feat0=f0.numpy(), feat1=f1.numpy(),
+             hw_c=np.array([hc, wc]), hw_i=np.array([hc * 8, wc * 8]),
+             b_ids=data["b_ids"].numpy(), i_ids=data["i_ids"].numpy(), j_ids=data["j_ids"].numpy(),
+             mconf=data["mconf"].numpy(), mkpts0_c=data["mkpts0_c"].numpy(), mkpts1_c=data["mkpts1_c"].numpy(),
+             conf_matrix=data["conf_matrix"].numpy())
+
+    # ---------------- CLS cosine + streaming top-3 (eval_linemod_json.py:71,94-101) ----------------
+    g = torch.Generator().manual_seed(9)
+    ref = torch.randn(1, 384, generator=g)
+    fea = torch.randn(40, 384, generator=g) + 0.5 * ref
+    fea[7] = fea[3]          # exact tie
+    fea[20] = -ref           # negative score never enters
+    scores = torch.cat([torch.nn.functional.cosine_similarity(ref, fea[i:i + 1], dim=1, eps=1e-8) for i in range(40)])
+    assert maxdiff(scores, cm_ref.cls_cosine(ref, fea)) < 1e-6
+    import numpy as _np
+    slots, top = _np.array([0, 0, 0], _np.float32), [-1, -1, -1]
+    for p in range(40):  # the reference's own loop, transcribed at the call site level
+        if (scores[p].item() > slots).any():
+            k = int(_np.argmin(slots)); slots[k] = scores[p].item(); top[k] = p
+    s2, t2 = cm_ref.streaming_top3(scores.numpy())
+    assert (s2 == slots).all() and list(t2) == top
+    np.savez(os.path.join(OUT, "top3.npz"), ref=ref.numpy(), fea=fea.numpy(), scores=scores.numpy(),
+             slot_scores=slots, slot_index=np.array(top))
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
