@@ -1,0 +1,119 @@
+/* pope_hip.h — C ABI of the MI355X-native (gfx950) POPE hot path.
+ *
+ * The reference (karltan0328/POPE) is pure Python on PyTorch: it has no FFI, its "operator
+ * interface" for this path is the call convention of two nn.Modules plus a namespace
+ * (SURVEY.md §8b).  Each entry point below names the reference call site it replaces; the
+ * Python mirror in pope_amd/ binds them with ctypes (see INTEGRATION.md for the stub a
+ * reference maintainer would add).
+ *
+ * Conventions: every pointer is a DEVICE pointer unless the name ends in _host; tensors are
+ * dense row-major fp32 in the reference's native layouts (torch Linear weight = [out, in]);
+ * `stream` is a hipStream_t (NULL = default stream); no entry point allocates, synchronises
+ * or keeps global state — workspaces are caller-provided (size query functions); return
+ * value 0 = OK, negative = error (pope_error_string).  All work is enqueued asynchronously.
+ */
+#ifndef POPE_HIP_H
+#define POPE_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POPE_ABI_VERSION 1
+
+enum {
+    POPE_EPI_BIAS = 0,        /* C = A.W^T + bias                         nn.Linear                     */
+    POPE_EPI_BIAS_GELU = 1,   /* C = gelu_erf(A.W^T + bias)               mlp.py:35-41 (fc1 + nn.GELU)  */
+    POPE_EPI_BIAS_LS_RES = 2  /* C = res + gamma*(A.W^T + bias)           block.py:105-106 + layer_scale.py:28 */
+};
+
+int pope_abi_version(void);
+const char* pope_error_string(int code);
+
+/* ---- op-level entry points (each is one kernel; used by the parity tests) ------------- */
+
+/* nn.LayerNorm(dim, eps) over the last dim — vision_transformer.py:90,230; block.py:56,68. */
+int pope_layernorm_f32(const float* x, const float* weight, const float* bias, float* y,
+                       int rows, int dim, float eps, void* stream);
+
+/* nn.Linear (+ fused epilogue) — attention.py:51,60; mlp.py:35-44.  A[M,K], W[N,K], C[M,N];
+ * gamma[N] and res[M,N] only for POPE_EPI_BIAS_LS_RES (res may alias C). */
+int pope_linear_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
+                    int epilogue, const float* gamma, const float* res, void* stream);
+
+/* PatchEmbed.forward + prepare_tokens_with_masks — patch_embed.py:69-82,
+ * vision_transformer.py:191-200.  img[B,3,H,W]; proj_w[dim, 3*patch*patch];
+ * posb[ntok, dim] = {cls_token + pos[0]; conv_bias + pos[n]} with pos already interpolated to
+ * the (H/patch, W/patch) grid; tokens[B, ntok, dim], ntok = 1 + (H/patch)*(W/patch). */
+int pope_patch_embed_f32(const float* img, const float* proj_w, const float* posb, float* tokens,
+                         int B, int H, int W, int patch, int dim, void* stream);
+
+/* Attention.forward core — attention.py:51-59: qkv[B,N,3,heads,64] -> out[B,N,heads*64],
+ * softmax((q*0.125) k^T) v. */
+int pope_attention_f32(const float* qkv, float* out, int B, int N, int heads, void* stream);
+
+/* F.cosine_similarity(ref[1,D], fea[P,D], dim=1, eps) — eval_linemod_json.py:94. */
+int pope_cls_cosine_f32(const float* ref, const float* fea, int P, int D, float eps, float* scores,
+                        void* stream);
+
+/* ---- whole-model entry point -------------------------------------------------------------- */
+
+typedef struct pope_vit_block_weights {   /* state-dict keys blocks.{i}.*  (device pointers) */
+    const float *norm1_w, *norm1_b;       /* norm1.weight/bias [dim]                          */
+    const float *qkv_w, *qkv_b;           /* attn.qkv.weight [3dim,dim], bias [3dim]          */
+    const float *proj_w, *proj_b;         /* attn.proj.weight [dim,dim], bias [dim]           */
+    const float *ls1;                     /* ls1.gamma [dim]                                  */
+    const float *norm2_w, *norm2_b;
+    const float *fc1_w, *fc1_b;           /* mlp.fc1.weight [hidden,dim]                      */
+    const float *fc2_w, *fc2_b;           /* mlp.fc2.weight [dim,hidden]                      */
+    const float *ls2;
+} pope_vit_block_weights;
+
+typedef struct pope_vit_weights {
+    int dim, depth, heads, patch, hidden;
+    const float* patch_w;                 /* patch_embed.proj.weight flattened [dim, 3*patch^2] */
+    const float *norm_w, *norm_b;         /* final norm                                         */
+    const pope_vit_block_weights* blocks_host; /* HOST array [depth] of device-pointer structs  */
+} pope_vit_weights;
+
+size_t pope_vit_workspace_bytes(int B, int ntok, int dim, int hidden);
+
+/* DinoVisionTransformer.forward_features — vision_transformer.py:221-236.
+ * Outputs: x_prenorm[B,ntok,dim] (also the residual stream, required) and x_norm[B,ntok,dim]
+ * (final LayerNorm; row 0 = x_norm_clstoken, rows 1.. = x_norm_patchtokens; may be NULL).
+ * n_taps/tap_blocks_host/tap_out_host: optional copies of the residual stream after the listed
+ * blocks (get_intermediate_layers, vision_transformer.py:238-288). */
+int pope_vit_forward_f32(const pope_vit_weights* w_host, const float* img, int B, int H, int W,
+                         const float* posb, float* x_prenorm, float* x_norm,
+                         int n_taps, const int* tap_blocks_host, float* const* tap_out_host,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- dense matcher --------------------------------------------------------------------------- */
+
+size_t pope_dense_match_workspace_bytes(int n, int L, int S);
+
+/* CoarseMatching.forward + get_coarse_match (eval, dual-softmax) —
+ * src/matcher/utils/coarse_matching.py:106-119,151-261.
+ * feat0[n,L,C], feat1[n,S,C]; grids (h0,w0),(h1,w1); scale = hw0_i[0]/hw0_c[0].
+ * conf_matrix[n,L,S]: published confidence matrix (required; it doubles as the sim buffer).
+ * Outputs have capacity n*L: b_ids,i_ids,j_ids (int64), mconf, mkpts0_c/mkpts1_c [.,2] (x,y);
+ * counts[n+1] (int32): matches per pair, then the total M (read it after synchronising). */
+int pope_dense_match_f32(const float* feat0, const float* feat1, int n, int L, int S, int C,
+                         int h0, int w0, int h1, int w1, float thr, int border_rm, float temperature,
+                         float scale, float* conf_matrix, long long* b_ids, long long* i_ids,
+                         long long* j_ids, float* mconf, float* mkpts0_c, float* mkpts1_c, int* counts,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- host-side helper ------------------------------------------------------------------------ */
+
+/* Streaming top-3 proposal vote — eval_linemod_json.py:71,95-101 (HOST pointers): slots start at
+ * 0; a proposal enters iff score > min(slots), replacing the first minimal slot. */
+int pope_streaming_top3_host(const float* scores_host, int P, float* slot_scores_host,
+                             long long* slot_index_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POPE_HIP_H */

@@ -1,0 +1,109 @@
+"""ctypes binding of libpope_hip.so (C ABI: include/pope_hip.h).
+
+The product path has NO fallback: if the library is missing or fails to load the import of
+``lib()`` raises, and every op raises on a non-zero status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libpope_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+c_ll_p = C.POINTER(C.c_longlong)
+
+
+class VitBlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
+        "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int), ("patch", C.c_int),
+                ("hidden", C.c_int), ("patch_w", C.c_void_p), ("norm_w", C.c_void_p),
+                ("norm_b", C.c_void_p), ("blocks_host", C.POINTER(VitBlockWeights))]
+
+
+# name -> (restype, argtypes); every symbol declared in include/pope_hip.h
+PROTOTYPES = {
+    "pope_abi_version": (C.c_int, []),
+    "pope_error_string": (C.c_char_p, [C.c_int]),
+    "pope_layernorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "pope_linear_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 3),
+    "pope_patch_embed_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
+    "pope_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pope_cls_cosine_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "pope_vit_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "pope_vit_forward_f32": (C.c_int, [C.POINTER(VitWeights), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int, c_int_p, C.POINTER(C.c_void_p),
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pope_dense_match_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "pope_dense_match_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_float,
+                                                                                  C.c_float] + [C.c_void_p] * 8
+                             + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pope_streaming_top3_host": (C.c_int, [c_float_p, C.c_int, c_float_p, c_ll_p]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libpope_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", _CSRC, "clean"], check=True, capture_output=True)
+    res = subprocess.run(["make", "-C", _CSRC, "-j4"], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libpope_hip.so failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+def lib():
+    """Load the shared library (once).  Raises if it is missing — there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(pope_amd has no fallback path)")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        if handle.pope_abi_version() != 1:
+            raise RuntimeError("libpope_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+class PopeHipError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    if status != 0:
+        raise PopeHipError(f"{what}: {lib().pope_error_string(status).decode()} (status {status})")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("pope_amd expects contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_of(device):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(t, what):
+    if not t.is_cuda:
+        raise PopeHipError(
+            f"{what}: tensor is on {t.device}; the pope_amd product path runs on the MI355X HIP kernels only "
+            "(no CPU fallback) — move the model/inputs to 'cuda'")

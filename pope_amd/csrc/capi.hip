@@ -1,0 +1,197 @@
+// C ABI (include/pope_hip.h) over the kernel launchers: argument checks, workspace carving and the
+// launch sequence of one DinoVisionTransformer forward.  No allocation, no synchronisation.
+#include "../../include/pope_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+__global__ __launch_bounds__(256) void cls_cosine_kernel(const float* __restrict__ ref, const float* __restrict__ fea,
+                                                          int P, int D, float eps, float* __restrict__ scores) {
+    // x.y / (max(|x|, eps) * max(|y|, eps)) — torch semantics, each norm clamped separately
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const float* f = fea + size_t(p) * D;
+    float dot = 0.f, nr = 0.f, nf = 0.f;
+    for (int i = lane; i < D; i += 64) {
+        const float a = ref[i], b = f[i];
+        dot += a * b;
+        nr += a * a;
+        nf += b * b;
+    }
+    dot = wave_sum(dot);
+    nr = wave_sum(nr);
+    nf = wave_sum(nf);
+    if (lane == 0) scores[p] = dot / (fmaxf(sqrtf(nr), eps) * fmaxf(sqrtf(nf), eps));
+}
+
+}  // namespace
+
+extern "C" {
+
+int pope_abi_version(void) { return POPE_ABI_VERSION; }
+
+const char* pope_error_string(int code) {
+    switch (code) {
+        case POPE_OK: return "ok";
+        case POPE_ERR_ARG: return "invalid argument (shape, alignment or null pointer)";
+        case POPE_ERR_LAUNCH: return "HIP launch failed";
+        case POPE_ERR_WORKSPACE: return "workspace too small";
+    }
+    return "unknown error";
+}
+
+int pope_layernorm_f32(const float* x, const float* weight, const float* bias, float* y, int rows, int dim,
+                       float eps, void* stream) {
+    if (!x || !weight || !bias || !y) return POPE_ERR_ARG;
+    return pope_launch_layernorm_f32(x, dim, weight, bias, y, dim, rows, dim, eps, static_cast<hipStream_t>(stream));
+}
+
+int pope_linear_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
+                    int epilogue, const float* gamma, const float* res, void* stream) {
+    if (!A || !W || !C || epilogue < 0 || epilogue > POPE_EPI_BIAS_LS_RES) return POPE_ERR_ARG;
+    GemmParams g = {};
+    g.A = A; g.W = W; g.bias = bias; g.C = C;
+    g.lda = K; g.ldw = K; g.ldc = N;
+    g.M = M; g.N = N; g.K = K;
+    g.epilogue = epilogue;
+    g.gamma = gamma; g.res = res; g.ldres = N;
+    return pope_launch_gemm_nt_f32(g, static_cast<hipStream_t>(stream));
+}
+
+int pope_patch_embed_f32(const float* img, const float* proj_w, const float* posb, float* tokens, int B, int H,
+                         int W, int patch, int dim, void* stream) {
+    if (!img || !proj_w || !posb || !tokens || B <= 0 || patch <= 0 || H % patch || W % patch) return POPE_ERR_ARG;
+    GemmParams g = {};
+    g.A = img; g.W = proj_w; g.C = tokens;
+    g.K = 3 * patch * patch;
+    g.ldw = g.K; g.ldc = dim;
+    g.ntok = 1 + (H / patch) * (W / patch);
+    g.M = B * g.ntok; g.N = dim;
+    g.epilogue = EPI_POSB;
+    g.posb = posb;
+    g.img_h = H; g.img_w = W; g.patch = patch; g.grid_w = W / patch;
+    return pope_launch_gemm_nt_f32(g, static_cast<hipStream_t>(stream));
+}
+
+int pope_attention_f32(const float* qkv, float* out, int B, int N, int heads, void* stream) {
+    if (!qkv || !out) return POPE_ERR_ARG;
+    return pope_launch_attention_f32(qkv, out, B, N, heads, static_cast<hipStream_t>(stream));
+}
+
+int pope_cls_cosine_f32(const float* ref, const float* fea, int P, int D, float eps, float* scores, void* stream) {
+    if (!ref || !fea || !scores || P <= 0 || D <= 0) return POPE_ERR_ARG;
+    hipLaunchKernelGGL(cls_cosine_kernel, dim3((P + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), ref, fea,
+                       P, D, eps, scores);
+    return pope_check_launch();
+}
+
+size_t pope_vit_workspace_bytes(int B, int ntok, int dim, int hidden) {
+    if (B <= 0 || ntok <= 0 || dim <= 0 || hidden <= 0) return 0;
+    const size_t rows = size_t(B) * ntok;
+    const size_t big = size_t(hidden) > size_t(4) * dim ? size_t(hidden) : size_t(4) * dim;
+    return align_up(rows * dim * sizeof(float), 256) + align_up(rows * big * sizeof(float), 256);
+}
+
+int pope_vit_forward_f32(const pope_vit_weights* w, const float* img, int B, int H, int W, const float* posb,
+                         float* x_prenorm, float* x_norm, int n_taps, const int* tap_blocks_host,
+                         float* const* tap_out_host, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!w || !img || !posb || !x_prenorm || !workspace || !w->blocks_host) return POPE_ERR_ARG;
+    if (w->dim != w->heads * 64 || w->patch <= 0 || H % w->patch || W % w->patch || B <= 0) return POPE_ERR_ARG;
+    if (n_taps < 0 || (n_taps > 0 && (!tap_blocks_host || !tap_out_host))) return POPE_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int dim = w->dim, hidden = w->hidden;
+    const int ntok = 1 + (H / w->patch) * (W / w->patch);
+    const int rows = B * ntok;
+    if (workspace_bytes < pope_vit_workspace_bytes(B, ntok, dim, hidden)) return POPE_ERR_WORKSPACE;
+
+    // workspace: xn [rows,dim] | big [rows, max(4dim, hidden)] = {qkv [rows,3dim], attn [rows,dim]} or fc1 out
+    char* ws = static_cast<char*>(workspace);
+    float* xn = reinterpret_cast<float*>(ws);
+    float* big = reinterpret_cast<float*>(ws + align_up(size_t(rows) * dim * sizeof(float), 256));
+    float* qkv = big;
+    float* att = big + size_t(rows) * 3 * dim;
+    float* hid = big;
+    float* x = x_prenorm;
+    const float eps = 1e-6f;  // vision_transformer.py:90
+
+    int rc = pope_patch_embed_f32(img, w->patch_w, posb, x, B, H, W, w->patch, dim, stream);
+    if (rc) return rc;
+    for (int i = 0; i < w->depth; ++i) {
+        const pope_vit_block_weights& k = w->blocks_host[i];
+        // x = x + ls1(attn(norm1(x)))                                      block.py:105
+        if ((rc = pope_launch_layernorm_f32(x, dim, k.norm1_w, k.norm1_b, xn, dim, rows, dim, eps, stream))) return rc;
+        if ((rc = pope_linear_f32(xn, k.qkv_w, k.qkv_b, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, stream))) return rc;
+        if ((rc = pope_launch_attention_f32(qkv, att, B, ntok, w->heads, stream))) return rc;
+        if ((rc = pope_linear_f32(att, k.proj_w, k.proj_b, x, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, stream))) return rc;
+        // x = x + ls2(mlp(norm2(x)))                                       block.py:106
+        if ((rc = pope_launch_layernorm_f32(x, dim, k.norm2_w, k.norm2_b, xn, dim, rows, dim, eps, stream))) return rc;
+        if ((rc = pope_linear_f32(xn, k.fc1_w, k.fc1_b, hid, rows, hidden, dim, EPI_BIAS_GELU, nullptr, nullptr, stream))) return rc;
+        if ((rc = pope_linear_f32(hid, k.fc2_w, k.fc2_b, x, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x, stream))) return rc;
+        for (int t = 0; t < n_taps; ++t)
+            if (tap_blocks_host[t] == i && tap_out_host[t])
+                if (hipMemcpyAsync(tap_out_host[t], x, size_t(rows) * dim * sizeof(float), hipMemcpyDeviceToDevice,
+                                   stream) != hipSuccess)
+                    return POPE_ERR_LAUNCH;
+    }
+    if (x_norm)
+        if ((rc = pope_launch_layernorm_f32(x, dim, w->norm_w, w->norm_b, x_norm, dim, rows, dim, eps, stream))) return rc;
+    return POPE_OK;
+}
+
+size_t pope_dense_match_workspace_bytes(int n, int L, int S) {
+    if (n <= 0 || L <= 0 || S <= 0) return 0;
+    const size_t nl = align_up(size_t(n) * L * 4, 256), ns = align_up(size_t(n) * S * 4, 256);
+    return 5 * nl + 3 * ns;  // row_max,row_sum,conf_rowmax,row_j,row_conf | col_max,col_sum,conf_colmax
+}
+
+int pope_dense_match_f32(const float* feat0, const float* feat1, int n, int L, int S, int C, int h0, int w0, int h1,
+                         int w1, float thr, int border_rm, float temperature, float scale, float* conf_matrix,
+                         long long* b_ids, long long* i_ids, long long* j_ids, float* mconf, float* mkpts0_c,
+                         float* mkpts1_c, int* counts, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!feat0 || !feat1 || !conf_matrix || !b_ids || !i_ids || !j_ids || !mconf || !mkpts0_c || !mkpts1_c ||
+        !counts || !workspace)
+        return POPE_ERR_ARG;
+    if (workspace_bytes < pope_dense_match_workspace_bytes(n, L, S)) return POPE_ERR_WORKSPACE;
+    const size_t nl = align_up(size_t(n) * L * 4, 256), ns = align_up(size_t(n) * S * 4, 256);
+    char* ws = static_cast<char*>(workspace);
+    MatchParams p = {};
+    p.feat0 = feat0; p.feat1 = feat1;
+    p.n = n; p.L = L; p.S = S; p.C = C;
+    p.h0 = h0; p.w0 = w0; p.h1 = h1; p.w1 = w1;
+    p.thr = thr; p.temperature = temperature; p.border = border_rm; p.scale = scale;
+    p.sim = conf_matrix;
+    p.row_max = reinterpret_cast<float*>(ws);
+    p.row_sum = reinterpret_cast<float*>(ws + nl);
+    p.conf_rowmax = reinterpret_cast<float*>(ws + 2 * nl);
+    p.row_j = reinterpret_cast<int*>(ws + 3 * nl);
+    p.row_conf = reinterpret_cast<float*>(ws + 4 * nl);
+    p.col_max = reinterpret_cast<float*>(ws + 5 * nl);
+    p.col_sum = reinterpret_cast<float*>(ws + 5 * nl + ns);
+    p.conf_colmax = reinterpret_cast<unsigned*>(ws + 5 * nl + 2 * ns);
+    p.counts = counts;
+    p.b_ids = b_ids; p.i_ids = i_ids; p.j_ids = j_ids;
+    p.mconf = mconf; p.mkpts0 = mkpts0_c; p.mkpts1 = mkpts1_c;
+    return pope_launch_dense_match_f32(p, static_cast<hipStream_t>(stream));
+}
+
+int pope_streaming_top3_host(const float* scores, int P, float* slot_scores, long long* slot_index) {
+    if (!scores || !slot_scores || !slot_index || P < 0) return POPE_ERR_ARG;
+    for (int k = 0; k < 3; ++k) { slot_scores[k] = 0.f; slot_index[k] = -1; }
+    for (int p = 0; p < P; ++p) {
+        const float s = scores[p];
+        if (s > slot_scores[0] || s > slot_scores[1] || s > slot_scores[2]) {
+            int k = 0;  // np.argmin: first minimum
+            if (slot_scores[1] < slot_scores[k]) k = 1;
+            if (slot_scores[2] < slot_scores[k]) k = 2;
+            slot_scores[k] = s;
+            slot_index[k] = p;
+        }
+    }
+    return POPE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// Shared device/host helpers for the gfx950 (CDNA4, MI355X) kernels of the POPE hot path.
+// Wave = 64 lanes everywhere; MFMA = v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, exact
+// k-ordered fmaf chain — the reference path is fp32 end to end).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define POPE_OK 0
+#define POPE_ERR_ARG (-1)
+#define POPE_ERR_LAUNCH (-2)
+#define POPE_ERR_WORKSPACE (-3)
+
+// C/D fragment map of every 32x32 MFMA on gfx950: register i of lane l holds
+// row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31.
+__device__ __forceinline__ int mfma32_row(int i, int half) { return (i & 3) + 8 * (i >> 2) + 4 * half; }
+
+__device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch).  Remap so that each XCD walks a
+// contiguous chunk of the logical tile space (neighbouring tiles share operand panels in
+// that XCD's private L2).  Bijective for any grid size; affects speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+static inline int pope_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? POPE_OK : POPE_ERR_LAUNCH;
+}

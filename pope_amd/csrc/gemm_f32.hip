@@ -1,0 +1,121 @@
+// fp32 "NT" GEMM on the gfx950 f32 MFMA:  C[M,N] = A[M,K] . W[N,K]^T  (+ fused epilogue).
+//
+// This one kernel family carries every Linear of the DINOv2 block — QKV, proj, FC1, FC2
+// (reference: dinov2/dinov2/layers/attention.py:51,60; mlp.py:35-44; layer_scale.py:27-28;
+// block.py:105-106) — and, with the im2col gather loader, the patch-embed conv
+// (patch_embed.py:69-82) fused with "+cls, +pos_embed" (vision_transformer.py:191-200).
+//
+// Tiling: 128x128 block tile, BK=32, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles,
+// v_mfma_f32_32x32x2_f32 (exact f32 fma chain).  Both operands are K-contiguous, so both are
+// staged identically: global -> registers (prefetch of tile t+1 issued before the MFMAs of
+// tile t) -> LDS rows padded to 36 floats (ds_read_b128 conflict-free: 9*r mod 16 is a
+// bijection on a 16-lane group).  The k order inside an 8-wide group is permuted
+// (lane half h takes k = 8j+4h+s at step s) so that one ds_read_b128 feeds four MFMAs; A and
+// W use the same permutation, so the sum is over the same products.
+#include "gemm_core.h"
+#include "kernels.h"
+
+namespace {
+
+using namespace gemm_core;
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    // nn.GELU() default = exact erf form
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <bool PATCH>
+__device__ __forceinline__ f32x4 load_a(const GemmParams& g, int row, int k) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row >= g.M || k >= g.K) return v;
+    if constexpr (!PATCH) {
+        return *reinterpret_cast<const f32x4*>(g.A + size_t(row) * g.lda + k);
+    } else {
+        // im2col on the fly: row = (image b, token n); token 0 is the cls slot (zero row, the
+        // epilogue adds cls+pos[0]); k = (c, i, j) over the patch, matching the flattened conv
+        // weight [dim][3][P][P].
+        const int b = row / g.ntok, n = row - b * g.ntok;
+        if (n == 0) return v;
+        const int p = n - 1, ph = p / g.grid_w, pw = p - ph * g.grid_w;
+        const int pp = g.patch * g.patch;
+        const float* img = g.A + size_t(b) * 3 * g.img_h * g.img_w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kk = k + e;
+            if (kk < g.K) {
+                const int c = kk / pp, rem = kk - c * pp, i = rem / g.patch, j = rem - i * g.patch;
+                v[e] = img[(size_t(c) * g.img_h + ph * g.patch + i) * g.img_w + pw * g.patch + j];
+            }
+        }
+        return v;
+    }
+}
+
+__device__ __forceinline__ f32x4 load_w(const GemmParams& g, int row, int k) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row >= g.N || k >= g.K) return v;
+    return *reinterpret_cast<const f32x4*>(g.W + size_t(row) * g.ldw + k);
+}
+
+template <int EPI, bool PATCH>
+__global__ __launch_bounds__(THREADS, 2) void gemm_nt_f32_kernel(const GemmParams g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+    f32x16 acc[2][2];
+    mainloop([&](int row, int k) { return load_a<PATCH>(g, m0 + row, k); },
+             [&](int row, int k) { return load_w(g, n0 + row, k); }, g.K, smem, acc);
+
+    // Epilogue straight from the accumulators: each register is one output row segment of 32
+    // consecutive columns per lane half (128 B per half-wave store).
+    for_each_output(acc, [&](int tr, int tc, float v) {
+        const int row = m0 + tr, col = n0 + tc;
+        if (row >= g.M || col >= g.N) return;
+        if constexpr (EPI == EPI_BIAS) {
+            v = v + (g.bias ? g.bias[col] : 0.f);
+        } else if constexpr (EPI == EPI_BIAS_GELU) {
+            v = gelu_erf(v + (g.bias ? g.bias[col] : 0.f));
+        } else if constexpr (EPI == EPI_BIAS_LS_RES) {
+            v = g.res[size_t(row) * g.ldres + col] + (v + (g.bias ? g.bias[col] : 0.f)) * g.gamma[col];
+        } else {  // EPI_POSB: + (pos_embed + conv bias | cls) table indexed by token
+            v = v + g.posb[size_t(row % g.ntok) * g.N + col];
+        }
+        g.C[size_t(row) * g.ldc + col] = v;
+    });
+}
+
+template <int EPI, bool PATCH>
+int launch(const GemmParams& g, hipStream_t stream) {
+    static bool attr_set = false;  // >64 KB dynamic LDS needs the opt-in once per kernel
+    auto kern = gemm_nt_f32_kernel<EPI, PATCH>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                int(LDS_BYTES)) != hipSuccess)
+            return POPE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS), LDS_BYTES, stream, g);
+    return pope_check_launch();
+}
+
+}  // namespace
+
+int pope_launch_gemm_nt_f32(const GemmParams& g, hipStream_t stream) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K & 3)) return POPE_ERR_ARG;
+    if (g.epilogue != EPI_POSB && ((g.lda & 3) || (reinterpret_cast<uintptr_t>(g.A) & 15))) return POPE_ERR_ARG;
+    if ((g.ldw & 3) || (reinterpret_cast<uintptr_t>(g.W) & 15)) return POPE_ERR_ARG;
+    switch (g.epilogue) {
+        case EPI_BIAS: return launch<EPI_BIAS, false>(g, stream);
+        case EPI_BIAS_GELU: return launch<EPI_BIAS_GELU, false>(g, stream);
+        case EPI_BIAS_LS_RES:
+            if (!g.gamma || !g.res) return POPE_ERR_ARG;
+            return launch<EPI_BIAS_LS_RES, false>(g, stream);
+        case EPI_POSB:
+            if (!g.posb || g.ntok <= 0 || g.patch <= 0) return POPE_ERR_ARG;
+            return launch<EPI_POSB, true>(g, stream);
+    }
+    return POPE_ERR_ARG;
+}

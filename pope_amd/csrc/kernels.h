@@ -1,0 +1,58 @@
+// Internal launcher interface between the kernel translation units and the C ABI (capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+enum GemmEpilogue {
+    EPI_BIAS = 0,         // C = A.W^T + bias
+    EPI_BIAS_GELU = 1,    // C = gelu_erf(A.W^T + bias)
+    EPI_BIAS_LS_RES = 2,  // C = res + gamma * (A.W^T + bias)      (LayerScale + residual)
+    EPI_POSB = 3,         // patch embed: C = im2col(img).W^T + posb[token]   (A = image)
+};
+
+struct GemmParams {
+    const float* A;     // [M, lda] row-major activations (EPI_POSB: image [B,3,H,W])
+    const float* W;     // [N, ldw] row-major weights (torch Linear layout, out x in)
+    const float* bias;  // [N] or null
+    float* C;           // [M, ldc]
+    int lda, ldw, ldc;
+    int M, N, K;
+    int epilogue;
+    const float* gamma;  // [N]      (EPI_BIAS_LS_RES)
+    const float* res;    // [M,ldres](EPI_BIAS_LS_RES; may alias C)
+    int ldres;
+    // patch-embed gather (EPI_POSB)
+    const float* posb;   // [ntok, N]: row 0 = cls_token + pos[0]; row n = conv bias + pos[n]
+    int ntok, img_h, img_w, patch, grid_w;
+};
+
+int pope_launch_gemm_nt_f32(const GemmParams& g, hipStream_t stream);
+
+// y[r,:] = LayerNorm(x[r,:]) * w + b over `dim` (multiple of 128, <= 2048), eps inside the sqrt.
+int pope_launch_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
+                              int rows, int dim, float eps, hipStream_t stream);
+
+// Multi-head softmax attention over qkv[B, N, 3, heads, 64] -> out[B, N, heads*64].
+int pope_launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream);
+
+struct MatchParams {
+    const float* feat0;  // [n, L, C]
+    const float* feat1;  // [n, S, C]
+    int n, L, S, C;
+    int h0, w0, h1, w1;  // coarse grids (L = h0*w0, S = h1*w1)
+    float thr, temperature;
+    int border;
+    float scale;         // hw0_i[0] / hw0_c[0]
+    float* sim;          // [n, L, S] workspace (sim, then conf in place)
+    float* row_max; float* row_sum;  // [n, L]
+    float* col_max; float* col_sum;  // [n, S]
+    unsigned* conf_colmax;           // [n, S] (float bits, conf > 0)
+    float* conf_rowmax;              // [n, L]
+    int* row_j;                      // [n, L]  matched column or -1
+    float* row_conf;                 // [n, L]
+    int* counts;                     // [n + 1] per-pair match counts, then total
+    // compacted outputs (capacity n * L)
+    long long* b_ids; long long* i_ids; long long* j_ids;
+    float* mconf; float* mkpts0; float* mkpts1;
+};
+int pope_launch_dense_match_f32(const MatchParams& p, hipStream_t stream);

@@ -1,0 +1,66 @@
+// Row LayerNorm, fp32 (nn.LayerNorm(dim, eps=1e-6): dinov2/dinov2/models/vision_transformer.py:90;
+// used as norm1/norm2 in block.py:56,68 and as the final norm, vision_transformer.py:230).
+// HBM-bound streaming op: one wave per row, the row lives in registers (float2 per lane per
+// 128 columns), two-pass mean / centred variance, wave-shuffle reductions, no LDS.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int NV>  // dim = NV * 128
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ y,
+                                                         int ldy, int rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + size_t(row) * ldx;
+    f32x2 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const f32x2*>(xr + i * 128 + lane * 2);
+        s += v[i][0] + v[i][1];
+    }
+    constexpr float inv_d = 1.0f / float(NV * 128);
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float d0 = v[i][0] - mean, d1 = v[i][1] - mean;
+        q += d0 * d0 + d1 * d1;
+    }
+    const float var = wave_sum(q) * inv_d;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float* yr = y + size_t(row) * ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 128 + lane * 2;
+        const f32x2 ww = *reinterpret_cast<const f32x2*>(w + c);
+        const f32x2 bb = *reinterpret_cast<const f32x2*>(b + c);
+        f32x2 o;
+        o[0] = (v[i][0] - mean) * rstd * ww[0] + bb[0];
+        o[1] = (v[i][1] - mean) * rstd * ww[1] + bb[1];
+        *reinterpret_cast<f32x2*>(yr + c) = o;
+    }
+}
+
+}  // namespace
+
+int pope_launch_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
+                              int rows, int dim, float eps, hipStream_t stream) {
+    if (rows <= 0 || dim <= 0 || (dim & 127) || dim > 2048 || (ldx & 1) || (ldy & 1)) return POPE_ERR_ARG;
+    const dim3 grid((rows + 3) / 4), block(256);
+#define POPE_LN_CASE(NV)                                                                              \
+    case NV:                                                                                          \
+        hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, stream, x, ldx, w, b, y, ldy, rows, eps); \
+        break;
+    switch (dim / 128) {
+        POPE_LN_CASE(1) POPE_LN_CASE(2) POPE_LN_CASE(3) POPE_LN_CASE(4) POPE_LN_CASE(6) POPE_LN_CASE(8)
+        POPE_LN_CASE(12) POPE_LN_CASE(16)
+        default: return POPE_ERR_ARG;
+    }
+#undef POPE_LN_CASE
+    return pope_check_launch();
+}

@@ -1,0 +1,279 @@
+"""MI355X-native DINOv2 ViT: drop-in for the reference ``DinoVisionTransformer``.
+
+Same constructor arguments, attribute names, state-dict keys (175 for ViT-S/14, loadable with
+``strict=True`` from a reference checkpoint) and call surface as
+``dinov2/dinov2/models/vision_transformer.py:45-295`` — ``model(x)``, ``model(x, is_training=True)``,
+``forward_features``, ``get_intermediate_layers`` — but the forward pass is ONE call into the HIP
+library (``pope_vit_forward_f32``): patch-embed GEMM (+cls +pos), 12 x [LN, QKV GEMM, flash
+attention, proj GEMM + LayerScale + residual, LN, FC1 GEMM + GELU, FC2 GEMM + LayerScale +
+residual], final LN — all hand-written gfx950 kernels on the fp32 MFMA.
+
+torch.nn modules are used here only as parameter containers (so ``.to()``, ``.eval()``,
+``state_dict()`` behave like the reference); they are never called.  There is no CPU fallback:
+calling the model on CPU tensors raises.
+"""
+import ctypes as C
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import check, ptr, require_cuda, stream_of
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.patches_resolution = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.patches_resolution[0] * self.patches_resolution[1]
+        self.in_chans, self.embed_dim = in_chans, embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias, proj_bias):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim, bias=proj_bias)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden, bias):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden, bias=bias)
+        self.fc2 = nn.Linear(hidden, dim, bias=bias)
+
+
+class _LayerScale(nn.Module):
+    def __init__(self, dim, init_values):
+        super().__init__()
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, proj_bias, ffn_bias, init_values):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim, num_heads, qkv_bias, proj_bias)
+        self.ls1 = _LayerScale(dim, init_values)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio), ffn_bias)
+        self.ls2 = _LayerScale(dim, init_values)
+
+
+class DinoVisionTransformer(nn.Module):
+    """HIP-backed ViT with the reference's interface (vision_transformer.py:45-295)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4.0, qkv_bias=True, ffn_bias=True, proj_bias=True, drop_path_rate=0.0,
+                 drop_path_uniform=False, init_values=None, ffn_layer="mlp", block_chunks=0, **_ignored):
+        super().__init__()
+        if in_chans != 3:
+            raise NotImplementedError("pope_amd: the patch-embed kernel is built for 3-channel images")
+        if embed_dim != num_heads * 64:
+            raise NotImplementedError("pope_amd: attention kernel is built for head_dim 64 (all DINOv2 archs)")
+        if ffn_layer != "mlp":
+            raise NotImplementedError("pope_amd: only the 'mlp' FFN (ViT-S/B/L) is on the hot path")
+        if not (qkv_bias and ffn_bias and proj_bias):
+            raise NotImplementedError("pope_amd: reference configs enable all biases (ssl_default_config.yaml:71-82)")
+        if block_chunks not in (0, None):
+            raise NotImplementedError("pope_amd: block_chunks is an FSDP training device; eval config uses 0")
+        self.num_features = self.embed_dim = embed_dim
+        self.num_tokens = 1
+        self.n_blocks = depth
+        self.num_heads = num_heads
+        self.patch_size = patch_size
+        self.patch_embed = _PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
+        # LayerScale is mandatory on this path (init_values=1e-5 in the eval config); None -> identity scale
+        gamma0 = init_values if init_values else 1.0
+        self.blocks = nn.ModuleList(
+            [_Block(embed_dim, num_heads, mlp_ratio, qkv_bias, proj_bias, ffn_bias, gamma0) for _ in range(depth)])
+        self.chunked_blocks = False
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.head = nn.Identity()
+        self.mask_token = nn.Parameter(torch.zeros(1, embed_dim))
+        self.init_weights()
+        self._wcache = None
+        self._posb_cache = {}
+        self._ws = None
+        for p in self.parameters():
+            p.requires_grad_(False)  # inference-only kernels
+
+    def init_weights(self):
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    # ---- cache management ----------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._wcache, self._posb_cache, self._ws = None, {}, None
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._wcache, self._posb_cache = None, {}
+        return out
+
+    def _weights(self):
+        dev_ptr = self.cls_token.data_ptr()
+        if self._wcache is not None and self._wcache[0] == dev_ptr:
+            return self._wcache[1]
+        tensors = []
+
+        def P(t):
+            t = t.detach()
+            if t.dtype != torch.float32:
+                raise TypeError("pope_amd kernels are fp32 (the reference path is fp32, SURVEY.md A15)")
+            t = t.contiguous()
+            tensors.append(t)
+            return t.data_ptr()
+
+        blocks = (_lib.VitBlockWeights * self.n_blocks)()
+        for i, b in enumerate(self.blocks):
+            blocks[i] = _lib.VitBlockWeights(
+                P(b.norm1.weight), P(b.norm1.bias), P(b.attn.qkv.weight), P(b.attn.qkv.bias),
+                P(b.attn.proj.weight), P(b.attn.proj.bias), P(b.ls1.gamma), P(b.norm2.weight), P(b.norm2.bias),
+                P(b.mlp.fc1.weight), P(b.mlp.fc1.bias), P(b.mlp.fc2.weight), P(b.mlp.fc2.bias), P(b.ls2.gamma))
+        w = _lib.VitWeights(self.embed_dim, self.n_blocks, self.num_heads, self.patch_size,
+                            self.blocks[0].mlp.fc1.weight.shape[0],
+                            P(self.patch_embed.proj.weight.reshape(self.embed_dim, -1)),
+                            P(self.norm.weight), P(self.norm.bias), blocks)
+        self._wcache = (dev_ptr, w, blocks, tensors)
+        return w
+
+    # ---- positional encoding (host plumbing, cached per (H, W)) -----------------------------
+    def interpolate_pos_encoding(self, x, w, h):
+        """vision_transformer.py:165-189.  As in the reference, `w` is the image HEIGHT and `h`
+        the image WIDTH (swapped names).  Evaluated in fp32 on the host so the
+        bicubic weights are bit-identical to the reference's CPU path."""
+        npatch = x.shape[1] - 1
+        N = self.pos_embed.shape[1] - 1
+        if npatch == N and w == h:
+            return self.pos_embed
+        pos = self.pos_embed.detach().float().cpu()
+        cls_pos, patch_pos = pos[:, 0], pos[:, 1:]
+        dim = pos.shape[-1]
+        g = int(math.sqrt(N))
+        w0, h0 = w // self.patch_size + 0.1, h // self.patch_size + 0.1
+        patch_pos = F.interpolate(patch_pos.reshape(1, g, g, dim).permute(0, 3, 1, 2),
+                                  scale_factor=(w0 / math.sqrt(N), h0 / math.sqrt(N)), mode="bicubic")
+        assert int(w0) == patch_pos.shape[-2] and int(h0) == patch_pos.shape[-1]
+        patch_pos = patch_pos.permute(0, 2, 3, 1).reshape(1, -1, dim)
+        return torch.cat((cls_pos.unsqueeze(0), patch_pos), dim=1).to(self.pos_embed.device)
+
+    def _posb(self, H, W, ntok):
+        """[ntok, dim] table added by the patch-embed epilogue: row 0 = cls_token + pos[0],
+        row n = conv bias + pos[n]."""
+        key = (H, W)
+        if key not in self._posb_cache:
+            dummy = torch.empty(1, ntok, 1)
+            pos = self.interpolate_pos_encoding(dummy, H, W)[0].detach().float().to(self.pos_embed.device)
+            posb = pos + self.patch_embed.proj.bias.detach()[None, :]
+            posb[0] = pos[0] + self.cls_token.detach()[0, 0]
+            self._posb_cache[key] = posb.contiguous()
+        return self._posb_cache[key]
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ---- forward --------------------------------------------------------------------------
+    def _run(self, x, taps=()):
+        require_cuda(x, "DinoVisionTransformer.forward")
+        require_cuda(self.cls_token, "DinoVisionTransformer weights")
+        if x.dtype != torch.float32:
+            raise TypeError("pope_amd DINOv2 expects float32 images")
+        x = x.contiguous()
+        B, nc, H, W = x.shape
+        p = self.patch_size
+        assert H % p == 0, f"Input image height {H} is not a multiple of patch height {p}"
+        assert W % p == 0, f"Input image width {W} is not a multiple of patch width: {p}"
+        ntok = 1 + (H // p) * (W // p)
+        dim = self.embed_dim
+        w = self._weights()
+        posb = self._posb(H, W, ntok)
+        L = _lib.lib()
+        nbytes = L.pope_vit_workspace_bytes(B, ntok, dim, w.hidden)
+        ws = self._workspace(nbytes, x.device)
+        x_pre = torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32)
+        x_norm = torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32)
+        tap_out = [torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32) for _ in taps]
+        tap_blocks = (C.c_int * max(1, len(taps)))(*taps)
+        tap_ptrs = (C.c_void_p * max(1, len(taps)))(*[t.data_ptr() for t in tap_out])
+        check(L.pope_vit_forward_f32(C.byref(w), ptr(x), B, H, W, ptr(posb), ptr(x_pre), ptr(x_norm),
+                                     len(taps), tap_blocks, tap_ptrs, C.c_void_p(ws.data_ptr()), ws.numel(),
+                                     stream_of(x.device)), "pope_vit_forward_f32")
+        return x_pre, x_norm, tap_out
+
+    def prepare_tokens_with_masks(self, x, masks=None):
+        """vision_transformer.py:191-200 (patch embed + cls + pos) as one HIP kernel."""
+        if masks is not None:
+            raise NotImplementedError("pope_amd: iBOT mask tokens are training-only (out of the hot path)")
+        from . import ops
+        B, nc, H, W = x.shape
+        ntok = 1 + (H // self.patch_size) * (W // self.patch_size)
+        self._weights()
+        return ops.patch_embed(x, self.patch_embed.proj.weight.detach(), self._posb(H, W, ntok), self.patch_size)
+
+    def forward_features(self, x, masks=None):
+        if isinstance(x, list):
+            raise NotImplementedError("pope_amd: nested-tensor (list) inputs are a training-time xformers path")
+        if masks is not None:
+            raise NotImplementedError("pope_amd: iBOT mask tokens are training-only (out of the hot path)")
+        x_pre, x_norm, _ = self._run(x)
+        return {"x_norm_clstoken": x_norm[:, 0], "x_norm_patchtokens": x_norm[:, 1:],
+                "x_prenorm": x_pre, "masks": masks}
+
+    def get_intermediate_layers(self, x, n=1, reshape=False, return_class_token=False, norm=True):
+        """vision_transformer.py:264-288."""
+        from . import ops
+        total = self.n_blocks
+        take = list(range(total - n, total)) if isinstance(n, int) else list(n)
+        _, _, outs = self._run(x, taps=take)
+        assert len(outs) == len(take), f"only {len(outs)} / {len(take)} blocks found"
+        if norm:
+            outs = [ops.layernorm(o, self.norm.weight.detach(), self.norm.bias.detach(), 1e-6) for o in outs]
+        cls = [o[:, 0] for o in outs]
+        outs = [o[:, 1:] for o in outs]
+        if reshape:
+            B, _, H, W = x.shape
+            outs = [o.reshape(B, H // self.patch_size, W // self.patch_size, -1).permute(0, 3, 1, 2).contiguous()
+                    for o in outs]
+        if return_class_token:
+            return tuple(zip(outs, cls))
+        return tuple(outs)
+
+    def forward(self, *args, is_training=False, **kwargs):
+        ret = self.forward_features(*args, **kwargs)
+        return ret if is_training else self.head(ret["x_norm_clstoken"])
+
+
+def vit_small(patch_size=16, **kw):
+    return DinoVisionTransformer(patch_size=patch_size, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, **kw)
+
+
+def vit_base(patch_size=16, **kw):
+    return DinoVisionTransformer(patch_size=patch_size, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, **kw)
+
+
+def vit_large(patch_size=16, **kw):
+    return DinoVisionTransformer(patch_size=patch_size, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, **kw)
+
+
+# the eval config of the reference (configs/eval/vits14_pretrain.yaml + ssl_default_config.yaml:71-82)
+build_vits14 = partial(vit_small, patch_size=14, img_size=518, init_values=1e-5, ffn_layer="mlp", block_chunks=0)

@@ -1,0 +1,102 @@
+"""Dense cross-image matcher on the HIP kernels: mirror of the reference ``CoarseMatching``
+(src/matcher/utils/coarse_matching.py:60-261) for the eval / dual-softmax path, plus a functional
+``dense_match`` used directly on DINOv2 patch tokens (BASELINE config 3).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, ptr, require_cuda, stream_of
+
+# src/matcher/utils/cvpr_ds_config.py:10-50, lower-cased as by lower_config(); plain data.
+default_cfg = {
+    "backbone_type": "ResNetFPN",
+    "resolution": (8, 2),
+    "fine_window_size": 5,
+    "fine_concat_coarse_feat": True,
+    "resnetfpn": {"initial_dim": 128, "block_dims": [128, 196, 256]},
+    "coarse": {"d_model": 256, "d_ffn": 256, "nhead": 8, "layer_names": ["self", "cross"] * 4,
+               "attention": "linear", "temp_bug_fix": False},
+    "match_coarse": {"thr": 0.2, "border_rm": 2, "match_type": "dual_softmax", "dsmax_temperature": 0.1,
+                     "skh_iters": 3, "skh_init_bin_score": 1.0, "skh_prefilter": True,
+                     "train_coarse_percent": 0.4, "train_pad_num_gt_min": 200},
+    "fine": {"d_model": 128, "d_ffn": 128, "nhead": 8, "layer_names": ["self", "cross"], "attention": "linear"},
+}
+
+
+@torch.no_grad()
+def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, temperature=0.1):
+    """All-pairs similarity -> dual softmax -> threshold/border/mutual-NN -> ordered matches.
+
+    feat0 [n,L,C], feat1 [n,S,C] fp32 on the GPU.  Returns the dict CoarseMatching publishes
+    (coarse_matching.py:145-148,239-259): conf_matrix, b_ids, i_ids, j_ids, gt_mask, m_bids,
+    mkpts0_c, mkpts1_c, mconf — plus `counts` (matches per pair, int32[n]).
+    One host synchronisation (to size the outputs), like torch.where in the reference."""
+    require_cuda(feat0, "dense_match")
+    require_cuda(feat1, "dense_match")
+    if feat0.dtype != torch.float32 or feat1.dtype != torch.float32:
+        raise TypeError("dense_match expects float32 features")
+    feat0, feat1 = feat0.contiguous(), feat1.contiguous()
+    n, L, Cc = feat0.shape
+    S = feat1.shape[1]
+    h0, w0 = int(hw0_c[0]), int(hw0_c[1])
+    h1, w1 = int(hw1_c[0]), int(hw1_c[1])
+    assert feat1.shape[0] == n and feat1.shape[2] == Cc and L == h0 * w0 and S == h1 * w1
+    dev = feat0.device
+    lib = _lib.lib()
+    ws_bytes = lib.pope_dense_match_workspace_bytes(n, L, S)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    conf = torch.empty(n, L, S, dtype=torch.float32, device=dev)
+    cap = n * L
+    b_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+    i_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+    j_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+    mconf = torch.empty(cap, dtype=torch.float32, device=dev)
+    mk0 = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+    mk1 = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+    counts = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    scale = hw0_i[0] / hw0_c[0]  # coarse_matching.py:242 (heights only)
+    check(lib.pope_dense_match_f32(ptr(feat0), ptr(feat1), n, L, S, Cc, h0, w0, h1, w1, float(thr), int(border_rm),
+                                   float(temperature), float(scale), ptr(conf), ptr(b_ids), ptr(i_ids), ptr(j_ids),
+                                   ptr(mconf), ptr(mk0), ptr(mk1), ptr(counts), C.c_void_p(ws.data_ptr()), ws_bytes,
+                                   stream_of(dev)), "pope_dense_match_f32")
+    counts_h = counts.cpu()  # sync point
+    m = int(counts_h[n])
+    b_ids, i_ids, j_ids, mconf = b_ids[:m], i_ids[:m], j_ids[:m], mconf[:m]
+    return {
+        "conf_matrix": conf,
+        "b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids,
+        "gt_mask": mconf == 0, "m_bids": b_ids,          # eval: mconf > thr, the `!= 0` filter is a no-op
+        "mkpts0_c": mk0[:m], "mkpts1_c": mk1[:m], "mconf": mconf,
+        "counts": counts_h[:n],
+    }
+
+
+class CoarseMatching(nn.Module):
+    """Drop-in for the reference module (eval, match_type='dual_softmax')."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.thr = config["thr"]
+        self.border_rm = config["border_rm"]
+        self.train_coarse_percent = config["train_coarse_percent"]
+        self.train_pad_num_gt_min = config["train_pad_num_gt_min"]
+        self.match_type = config["match_type"]
+        if self.match_type == "dual_softmax":
+            self.temperature = config["dsmax_temperature"]
+        else:
+            raise NotImplementedError("pope_amd: only the dual_softmax matcher is on the hot path "
+                                      "(default_cfg; sinkhorn needs the absent superglue.py in the reference too)")
+
+    def forward(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
+        if mask_c0 is not None or "mask0" in data:
+            raise NotImplementedError("pope_amd: padding masks are a training-time path (matcher.py:62-64)")
+        if self.training:
+            raise NotImplementedError("pope_amd: inference only (call .eval())")
+        out = dense_match(feat_c0, feat_c1, data["hw0_c"], data["hw1_c"], data["hw0_i"], self.thr, self.border_rm,
+                          self.temperature)
+        out.pop("counts")
+        data.update(out)

@@ -1,0 +1,92 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/pope_hip.h
+declares (no compute calls without a GPU); host-only helpers behave like the oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from pope_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pope_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pope_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(hip_lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(hip_lib, name), f"{name} declared in pope_hip.h but not exported"
+    assert sorted(_lib.PROTOTYPES) == declared  # the ctypes table covers the whole header
+
+
+def test_header_is_plain_c():
+    # the boundary must be consumable from C (no torch / C++ types in signatures)
+    src = "#include \"pope_hip.h\"\nint main(void){return pope_abi_version()==POPE_ABI_VERSION?0:1;}\n"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I",
+                        os.path.join(ROOT, "include"), "-x", "c", "-"], input=src, text=True, capture_output=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_code_object_is_gfx950():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _lib.LIB_PATH],
+                         capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_abi_version_and_errors(hip_lib):
+    assert hip_lib.pope_abi_version() == 1
+    assert hip_lib.pope_error_string(0) == b"ok"
+    assert b"workspace" in hip_lib.pope_error_string(-3)
+
+
+def test_workspace_queries(hip_lib):
+    # B=64 images of 1531 tokens: xn + max(qkv+attn, fc1) = 5*dim floats per token
+    n = hip_lib.pope_vit_workspace_bytes(64, 1531, 384, 1536)
+    assert n >= 64 * 1531 * 5 * 384 * 4 and n < 64 * 1531 * 5 * 384 * 4 + 1024
+    assert hip_lib.pope_vit_workspace_bytes(0, 1, 1, 1) == 0
+    assert hip_lib.pope_dense_match_workspace_bytes(2, 1530, 1530) >= 8 * 2 * 1530 * 4
+
+
+def test_argument_validation_without_gpu(hip_lib):
+    # invalid arguments are rejected before any HIP call is made
+    assert hip_lib.pope_layernorm_f32(None, None, None, None, 4, 384, 1e-6, None) == -1
+    assert hip_lib.pope_linear_f32(None, None, None, None, 1, 1, 4, 0, None, None, None) == -1
+    assert hip_lib.pope_attention_f32(None, None, 1, 1, 6, None) == -1
+
+
+def test_streaming_top3_host_matches_oracle(golden_dir):
+    from oracle import coarse_match_ref as cm
+    from pope_amd import ops
+    fx = np.load(os.path.join(golden_dir, "top3.npz"))
+    slots, idx = ops.streaming_top3(fx["scores"])
+    assert np.array_equal(slots, fx["slot_scores"]) and np.array_equal(idx, fx["slot_index"])
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        s = rng.uniform(-0.2, 1.0, size=rng.integers(0, 12)).astype(np.float32)
+        s[rng.random(s.size) < 0.3] = 0.5  # ties
+        a, b = ops.streaming_top3(s)
+        c, d = cm.streaming_top3(s)
+        assert np.array_equal(a, c) and np.array_equal(b, d)
+
+
+def test_product_fails_loudly_on_cpu(sd0):
+    import torch
+    from pope_amd.dinov2_utils import load_dinov2_model
+    from pope_amd._lib import PopeHipError
+    model = load_dinov2_model(state_dict=sd0)
+    assert len(model.state_dict()) == 175
+    with pytest.raises(PopeHipError):
+        model(torch.zeros(1, 3, 28, 28))
+
+
+def test_product_never_imports_oracle():
+    import pathlib
+    for p in pathlib.Path(ROOT, "pope_amd").rglob("*.py"):
+        assert "oracle" not in p.read_text().replace("no CPU oracle", ""), p

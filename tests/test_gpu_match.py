@@ -1,0 +1,99 @@
+"""GPU: dense matcher through the C ABI — identical match indices to the reference fixtures,
+mconf within 1e-5, ordering, ties, border capacity, empty output."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(hip_lib):
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_loftr_shaped_fixture_indices_identical(dev, golden_dir):
+    from pope_amd.matcher import dense_match
+    fx = np.load(os.path.join(golden_dir, "match_loftr256.npz"))
+    hw_c, hw_i = tuple(int(v) for v in fx["hw_c"]), tuple(int(v) for v in fx["hw_i"])
+    out = dense_match(torch.from_numpy(fx["feat0"]).to(dev), torch.from_numpy(fx["feat1"]).to(dev), hw_c, hw_c, hw_i)
+    for k in ("b_ids", "i_ids", "j_ids"):
+        assert out[k].dtype == torch.int64
+        assert np.array_equal(out[k].cpu().numpy(), fx[k]), k
+    np.testing.assert_allclose(out["mconf"].cpu().numpy(), fx["mconf"], rtol=1e-4, atol=1e-6)
+    assert np.array_equal(out["mkpts0_c"].cpu().numpy(), fx["mkpts0_c"])
+    assert np.array_equal(out["mkpts1_c"].cpu().numpy(), fx["mkpts1_c"])
+    np.testing.assert_allclose(out["conf_matrix"].cpu().numpy(), fx["conf_matrix"], rtol=1e-4, atol=1e-7)
+
+
+def test_coarse_matching_module_updates_dict(dev, golden_dir):
+    from pope_amd.matcher import CoarseMatching, default_cfg
+    fx = np.load(os.path.join(golden_dir, "match_loftr256.npz"))
+    hw_c, hw_i = tuple(int(v) for v in fx["hw_c"]), tuple(int(v) for v in fx["hw_i"])
+    data = {"hw0_i": hw_i, "hw1_i": hw_i, "hw0_c": hw_c, "hw1_c": hw_c}
+    m = CoarseMatching(default_cfg["match_coarse"]).eval()
+    assert m(torch.from_numpy(fx["feat0"]).to(dev), torch.from_numpy(fx["feat1"]).to(dev), data) is None
+    for k in ("conf_matrix", "b_ids", "i_ids", "j_ids", "gt_mask", "m_bids", "mkpts0_c", "mkpts1_c", "mconf"):
+        assert k in data
+    assert np.array_equal(data["j_ids"].cpu().numpy(), fx["j_ids"])
+
+
+@pytest.mark.parametrize("name", ["match_224", "match_476x630"])
+def test_dinov2_token_matching_end_to_end(dev, sd0, golden_dir, name):
+    """extract (HIP ViT) + match (HIP matcher) vs the reference pipeline's fixture."""
+    from pope_amd import synth
+    from pope_amd.dinov2_utils import load_dinov2_model
+    from pope_amd.matcher import dense_match
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    n, H, W = (int(v) for v in fx["shape"])
+    model = load_dinov2_model(state_dict=sd0).to(dev)
+    i0, i1 = synth.synthetic_pairs(n, H, W, seed=int(fx["pair_seed"]))
+    f0 = model(i0.to(dev), is_training=True)["x_norm_patchtokens"].contiguous()
+    f1 = model(i1.to(dev), is_training=True)["x_norm_patchtokens"].contiguous()
+    np.testing.assert_allclose(f0.cpu()[:, ::16].numpy(), fx["feat0_rows"], rtol=0, atol=2e-4)
+    hw_c = (H // 14, W // 14)
+    out = dense_match(f0, f1, hw_c, hw_c, (H, W))
+    assert np.array_equal(out["b_ids"].cpu().numpy(), fx["b_ids"])
+    assert np.array_equal(out["i_ids"].cpu().numpy(), fx["i_ids"])
+    assert np.array_equal(out["j_ids"].cpu().numpy(), fx["j_ids"])
+    np.testing.assert_allclose(out["mconf"].cpu().numpy(), fx["mconf"], rtol=0, atol=2e-3)
+    assert np.array_equal(out["mkpts0_c"].cpu().numpy(), fx["mkpts0_c"])
+    conf = out["conf_matrix"]
+    assert np.array_equal(conf.max(2)[1].cpu().numpy()[fx["b_ids"], fx["i_ids"]], fx["j_ids"])
+    assert abs(float(conf.double().sum()) - float(fx["conf_sum"][0])) < 1e-2 * float(fx["conf_sum"][0])
+
+
+def test_matcher_vs_oracle_random_shapes(dev):
+    from oracle import coarse_match_ref as cm
+    from pope_amd.matcher import dense_match
+    g = torch.Generator().manual_seed(5)
+    for (n, h0, w0, h1, w1, C) in [(1, 6, 7, 6, 7, 32), (3, 9, 11, 8, 13, 64), (2, 34, 45, 34, 45, 384), (1, 5, 5, 12, 9, 256)]:
+        L, S = h0 * w0, h1 * w1
+        f0 = torch.randn(n, L, C, generator=g) * 3
+        idx = torch.randint(0, L, (n, S), generator=g)
+        f1 = torch.gather(f0, 1, idx[..., None].expand(-1, -1, C)) + 0.2 * torch.randn(n, S, C, generator=g)
+        want = cm.dense_match(f0, f1, (h0, w0), (h1, w1), (h0 * 8, w0 * 8))
+        got = dense_match(f0.to(dev), f1.to(dev), (h0, w0), (h1, w1), (h0 * 8, w0 * 8))
+        for k in ("b_ids", "i_ids", "j_ids"):
+            assert np.array_equal(got[k].cpu().numpy(), want[k].numpy()), (k, n, h0, w0)
+        np.testing.assert_allclose(got["mconf"].cpu().numpy(), want["mconf"].numpy(), rtol=1e-4, atol=1e-6)
+        assert np.array_equal(got["mkpts1_c"].cpu().numpy(), want["mkpts1_c"].numpy())
+
+
+def test_border_capacity_ties_and_empty(dev):
+    from pope_amd.matcher import dense_match
+    g = torch.Generator().manual_seed(1)
+    h, w = 9, 11
+    f = (torch.randn(1, h * w, 64, generator=g) * 4).to(dev)
+    out = dense_match(f, f, (h, w), (h, w), (h * 14, w * 14))
+    assert len(out["i_ids"]) == (h - 4) * (w - 4)
+    assert bool((out["i_ids"] == out["j_ids"]).all())
+    key = out["b_ids"] * 10**6 + out["i_ids"]
+    assert bool((key[1:] > key[:-1]).all())
+    f0 = torch.randn(2, 36, 32, generator=g).to(dev)
+    f1 = torch.randn(2, 36, 32, generator=g).to(dev)
+    out = dense_match(f0, f1, (6, 6), (6, 6), (48, 48))
+    assert len(out["i_ids"]) == 0 and out["mkpts0_c"].shape == (0, 2) and list(out["counts"]) == [0, 0]

@@ -1,0 +1,131 @@
+"""GPU: every HIP kernel against a plain torch fp32 reference of the same op (computed on the
+CPU, like the reference's own path) — called through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(hip_lib):
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _close(got, want, atol, rtol=0.0):
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 384), (7, 384), (197 * 2, 384), (1531, 384), (33, 768), (5, 1024)])
+def test_layernorm(dev, rows, dim):
+    from pope_amd import ops
+    x = _rand(rows, dim, seed=1, scale=3.0) + 0.7
+    w, b = 1 + 0.1 * _rand(dim, seed=2), 0.1 * _rand(dim, seed=3)
+    want = F.layer_norm(x, (dim,), w, b, 1e-6)
+    got = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-6)
+    _close(got, want, atol=2e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 384, 384), (130, 1152, 384), (394, 1536, 384), (257, 384, 1536),
+                                    (1531, 1152, 384), (129, 100, 36)])
+def test_linear_bias(dev, M, N, K):
+    from pope_amd import ops
+    a, w, b = _rand(M, K, seed=4), _rand(N, K, seed=5, scale=K ** -0.5), _rand(N, seed=6)
+    want = F.linear(a, w, b)
+    got = ops.linear(a.to(dev), w.to(dev), b.to(dev))
+    _close(got, want, atol=1e-5, rtol=1e-5)
+
+
+def test_linear_is_exact_fma_chain_on_integers(dev):
+    # integer-valued operands: every product and partial sum is exact in fp32, so any operand-map
+    # or k-permutation error shows up as a wrong integer (asymmetric W: catches transposes)
+    from pope_amd import ops
+    g = torch.Generator().manual_seed(7)
+    a = torch.randint(-4, 5, (200, 96), generator=g).float()
+    w = torch.randint(-4, 5, (136, 96), generator=g).float()
+    got = ops.linear(a.to(dev), w.to(dev))
+    assert torch.equal(got.cpu(), a @ w.t())
+
+
+def test_linear_gelu(dev):
+    from pope_amd import ops
+    a, w, b = _rand(300, 384, seed=8), _rand(1536, 384, seed=9, scale=384 ** -0.5), _rand(1536, seed=10)
+    want = F.gelu(F.linear(a, w, b))
+    got = ops.linear(a.to(dev), w.to(dev), b.to(dev), epilogue=ops.EPI_BIAS_GELU)
+    _close(got, want, atol=1e-5, rtol=1e-5)
+
+
+def test_linear_layerscale_residual_inplace(dev):
+    from pope_amd import ops
+    a, w, b = _rand(300, 1536, seed=11), _rand(384, 1536, seed=12, scale=1536 ** -0.5), _rand(384, seed=13)
+    gamma, res = 0.3 + 0.1 * _rand(384, seed=14), _rand(300, 384, seed=15)
+    want = res + F.linear(a, w, b) * gamma
+    x = res.to(dev).clone()
+    got = ops.linear(a.to(dev), w.to(dev), b.to(dev), epilogue=ops.EPI_BIAS_LS_RES, gamma=gamma.to(dev), res=x, out=x)
+    assert got.data_ptr() == x.data_ptr()
+    _close(got, want, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 28, 42), (1, 196, 196), (2, 224, 224), (1, 476, 630)])
+def test_patch_embed_tokens(dev, sd0, B, H, W):
+    from oracle import dinov2_ref
+    from pope_amd import synth
+    from pope_amd.dinov2_utils import load_dinov2_model
+    model = load_dinov2_model(state_dict=sd0).to(dev)
+    x = synth.synthetic_images(B, H, W, seed=21)
+    want = dinov2_ref.prepare_tokens(sd0, x)
+    got = model.prepare_tokens_with_masks(x.to(dev))
+    _close(got, want, atol=2e-5)
+
+
+def test_patch_embed_rejects_non_multiple(dev, sd0):
+    from pope_amd.dinov2_utils import load_dinov2_model
+    model = load_dinov2_model(state_dict=sd0).to(dev)
+    with pytest.raises(AssertionError, match="not a multiple of patch"):
+        model(torch.zeros(1, 3, 480, 640, device=dev))
+
+
+@pytest.mark.parametrize("B,N,heads", [(1, 1, 6), (2, 31, 6), (2, 64, 6), (1, 197, 6), (2, 257, 6), (1, 1531, 6),
+                                        (1, 130, 12)])
+def test_attention(dev, B, N, heads):
+    from pope_amd import ops
+    D = heads * 64
+    qkv = _rand(B, N, 3 * D, seed=30 + N, scale=1.5)
+    q, k, v = qkv.reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    want = (((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B, N, D)
+    got = ops.attention(qkv.to(dev), heads)
+    _close(got, want, atol=2e-5, rtol=1e-5)
+
+
+def test_attention_online_softmax_rescale_branch(dev):
+    # force the running max to jump at a late key tile (spiked key), so the rescale of O and l is
+    # exercised with a large factor (guide rule: a rare data-dependent branch needs its own test)
+    from pope_amd import ops
+    B, N, heads = 1, 300, 6
+    qkv = _rand(B, N, 3 * heads * 64, seed=99, scale=0.5)
+    t = qkv.view(B, N, 3, heads, 64)
+    t[0, 250, 1] = t[0, 10, 0] * 40.0   # key 250 aligned with query 10: score jumps by ~+100
+    t[0, 290, 1] = t[0, 70, 0] * -40.0  # and a strongly negative one
+    q, k, v = t.permute(2, 0, 3, 1, 4)
+    want = (((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B, N, heads * 64)
+    got = ops.attention(qkv.to(dev), heads)
+    _close(got, want, atol=2e-5, rtol=1e-5)
+
+
+def test_cls_cosine_and_top3(dev, golden_dir):
+    import os
+    from pope_amd import ops
+    fx = np.load(os.path.join(golden_dir, "top3.npz"))
+    scores = ops.cls_cosine(torch.from_numpy(fx["ref"]).to(dev), torch.from_numpy(fx["fea"]).to(dev))
+    np.testing.assert_allclose(scores.cpu().numpy(), fx["scores"], rtol=0, atol=1e-6)
+    slots, idx = ops.streaming_top3(scores.cpu().numpy())
+    assert np.array_equal(idx, fx["slot_index"])  # identical top-3 slot assignment
+    z = ops.cls_cosine(torch.tensor([[1e-9, 0, 0]], device=dev), torch.tensor([[2e-9, 0, 0]], device=dev))
+    assert abs(float(z) - 0.02) < 1e-6
