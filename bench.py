@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""bench.py — image-pairs/s of the POPE hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic 640x480 pairs resident in HBM:
+DINOv2-S/14 patch descriptors for both images of every pair (476x630 centre crop, 1531 tokens) +
+dense dual-softmax / mutual-NN matching of the 1530x1530 descriptor pairs (BASELINE config 3:
+"Extract + dense cosine-sim matcher + mutual-NN on 640x480 pairs, batch=128").
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Pairs are independent: every rank works on its own batch (weak scaling, no data-path collective);
+the only exchange is the RCCL all_gather of per-pair match counts at the end of each step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H_IMG, W_IMG, PATCH = 476, 630, 14
+NTOK = 1 + (H_IMG // PATCH) * (W_IMG // PATCH)  # 1531
+DIM, HEADS, HIDDEN, DEPTH = 384, 6, 1536, 12
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_image(np_=NTOK - 1):
+    n = np_ + 1
+    return 451584 * np_ + 12 * (3538944 * n + 1536 * n * n)
+
+
+def flops_per_pair():
+    L = NTOK - 1
+    return 2 * flops_per_image() + 2 * L * L * DIM
+
+
+def gpu_pairs(n_pairs, device, seed):
+    """Seeded synthetic pairs generated on the device: uniform[0,1) 640x480 frame,
+    centre crop 476x630, ImageNet normalisation; img1 = roll(img0,(14,28)) + N(0,0.1^2)."""
+    from pope_amd.synth import IMAGENET_MEAN, IMAGENET_STD
+    g = torch.Generator(device=device).manual_seed(seed)
+    mean = torch.tensor(IMAGENET_MEAN, device=device).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=device).view(1, 3, 1, 1)
+    img = torch.rand(n_pairs, 3, 480, 640, generator=g, device=device)
+    img0 = ((img[:, :, 2:2 + H_IMG, 5:5 + W_IMG] - mean) / std).contiguous()
+    img1 = torch.roll(img0, shifts=(14, 28), dims=(2, 3))
+    img1 = (img1 + 0.1 * torch.randn(img1.shape, generator=g, device=device)).contiguous()
+    return img0, img1
+
+
+def time_kernel(fn, reps=6):
+    """Average duration (ms) of one launch, HIP events on the launch stream (torch's current stream)."""
+    fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return sum(ts) / len(ts)
+
+
+def kernel_table(model, device, chunk):
+    """Per-kernel live timings at the bench shapes (one ViT chunk = `chunk` images)."""
+    from pope_amd import ops
+    rows = chunk * NTOK
+    g = torch.Generator(device=device).manual_seed(1)
+    blk = model.blocks[5]
+    x = torch.randn(rows, DIM, generator=g, device=device)
+    qkv = torch.randn(chunk, NTOK, 3 * DIM, generator=g, device=device)
+    hid = torch.randn(rows, HIDDEN, generator=g, device=device)
+    out_d = torch.zeros(rows, DIM, device=device)
+    out_q = torch.empty(rows, 3 * DIM, device=device)
+    out_h = torch.empty(rows, HIDDEN, device=device)
+    tab = []
+
+    def add(name, fn, flops, bytes_, launches):
+        ms = time_kernel(fn)
+        tab.append({"kernel": name, "ms": round(ms, 4), "launches_per_step": launches,
+                    "tflops": round(flops / ms / 1e9, 2) if flops else None,
+                    "gbs": round(bytes_ / ms / 1e6, 1), "flops": flops, "bytes": bytes_})
+
+    per_step = lambda n_chunks: n_chunks * DEPTH
+    add("attention_f32", lambda: ops.attention(qkv, HEADS), 4 * chunk * NTOK * NTOK * DIM,
+        rows * 4 * DIM * 4, 1)
+    add("gemm_qkv(bias)", lambda: ops.linear(x, blk.attn.qkv.weight, blk.attn.qkv.bias, out=out_q),
+        2 * rows * DIM * 3 * DIM, rows * 4 * DIM * 4, 1)
+    add("gemm_proj(ls_res)", lambda: ops.linear(x, blk.attn.proj.weight, blk.attn.proj.bias, ops.EPI_BIAS_LS_RES,
+                                                 blk.ls1.gamma, out_d, out=out_d),
+        2 * rows * DIM * DIM, rows * 3 * DIM * 4, 1)
+    add("gemm_fc1(gelu)", lambda: ops.linear(x, blk.mlp.fc1.weight, blk.mlp.fc1.bias, ops.EPI_BIAS_GELU, out=out_h),
+        2 * rows * DIM * HIDDEN, rows * (DIM + HIDDEN) * 4, 1)
+    add("gemm_fc2(ls_res)", lambda: ops.linear(hid, blk.mlp.fc2.weight, blk.mlp.fc2.bias, ops.EPI_BIAS_LS_RES,
+                                                blk.ls2.gamma, out_d, out=out_d),
+        2 * rows * DIM * HIDDEN, rows * (HIDDEN + 2 * DIM) * 4, 1)
+    add("layernorm", lambda: ops.layernorm(x, blk.norm1.weight, blk.norm1.bias), 0, rows * 2 * DIM * 4, 2)
+    return tab
+
+
+def cpu_baseline(n_pairs):
+    """The CPU oracle (torch fp32 restatement validated against the reference) on the host cores."""
+    from oracle import coarse_match_ref, dinov2_ref
+    from pope_amd import synth
+    # host-core share of this process (the GPU box gives a 1-GPU job 16 of its cores)
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    sd = synth.synthetic_state_dict(seed=0)
+    i0, i1 = synth.synthetic_pairs(n_pairs, H_IMG, W_IMG, seed=0)
+    hw_c = (H_IMG // PATCH, W_IMG // PATCH)
+
+    def run():
+        f0 = dinov2_ref.forward_features(sd, i0)["x_norm_patchtokens"]
+        f1 = dinov2_ref.forward_features(sd, i1)["x_norm_patchtokens"]
+        return coarse_match_ref.dense_match(f0, f1, hw_c, hw_c, (H_IMG, W_IMG))
+
+    run()  # warm-up
+    best = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        out = run()
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(n_pairs / best, 4), "unit": "image-pairs/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{n_pairs} pairs 476x630 (batch {n_pairs} per forward), 1 warm-up + best of 2, "
+                      f"{int(len(out['i_ids']))} matches"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU per step (BASELINE config 3)")
+    ap.add_argument("--chunk", type=int, default=64, help="images per ViT launch sequence (BASELINE config 2)")
+    ap.add_argument("--cpu-pairs", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-table", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
+
+    from pope_amd import synth
+    from pope_amd.dinov2_utils import load_dinov2_model
+    from pope_amd.pipeline import PairPipeline, gather_counts
+
+    model = load_dinov2_model(state_dict=synth.synthetic_state_dict(seed=0)).to(device)
+    pipe = PairPipeline(model, chunk=args.chunk)
+    img0, img1 = gpu_pairs(args.pairs, device, seed=rank)
+
+    def step():
+        out = pipe(img0, img1)
+        counts = gather_counts(out["counts"].to(device))  # the only exchange: per-pair match counts
+        return out, counts
+
+    for _ in range(args.warmup):
+        out, counts = step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, counts = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    total_pairs = args.pairs * world * args.steps
+    value = total_pairs / elapsed
+    result = {
+        "metric": "image-pairs/s (DINOv2-S/14 extract+match, 640x480)",
+        "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "extract(2 x DINOv2-S/14 @476x630 centre crop of 640x480, 1531 tokens) + dense "
+                               "dual-softmax mutual-NN match (1530x1530x384) per pair",
+                   "pairs_per_gpu_per_step": args.pairs, "vit_chunk_images": args.chunk,
+                   "weights": "seeded synthetic, reference state-dict layout",
+                   "parallelism": f"pairs sharded over {world} GPU(s); RCCL all_gather of match counts"},
+        "gflop_per_pair": round(flops_per_pair() / 1e9, 3),
+        "achieved_tflops_whole_step": round(value * flops_per_pair() / 1e12 / world, 2),
+        "matches_per_pair_mean": round(float(counts.float().mean()), 1),
+    }
+    if rank == 0 and not args.no_kernel_table:
+        tab = kernel_table(model, device, args.chunk)
+        n_chunks = 2 * args.pairs // args.chunk
+        for t in tab:
+            t["ms_per_step"] = round(t["ms"] * t["launches_per_step"] * n_chunks * DEPTH, 3)
+        dom = max((t for t in tab if t["flops"]), key=lambda t: t["ms_per_step"])
+        result["roofline"] = {
+            "kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "flops_per_launch": dom["flops"], "ms_per_launch": dom["ms"],
+            "note": "f32-in/f32-acc MFMA (v_mfma_f32_32x32x2_f32) dense peak; HIP events on the launch stream",
+        }
+        result["kernels"] = [{k: t[k] for k in ("kernel", "ms", "ms_per_step", "tflops", "gbs")} for t in tab]
+    if rank == 0 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

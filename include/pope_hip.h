@@ -96,11 +96,14 @@ size_t pope_dense_match_workspace_bytes(int n, int L, int S);
 
 /* CoarseMatching.forward + get_coarse_match (eval, dual-softmax) —
  * src/matcher/utils/coarse_matching.py:106-119,151-261.
- * feat0[n,L,C], feat1[n,S,C]; grids (h0,w0),(h1,w1); scale = hw0_i[0]/hw0_c[0].
+ * feat0[n,L,C], feat1[n,S,C] with `stride0`/`stride1` elements between consecutive pairs (L*C / S*C
+ * when dense; larger when the features are the patch rows of an x_norm[B,1+L,C] buffer);
+ * grids (h0,w0),(h1,w1); scale = hw0_i[0]/hw0_c[0].
  * conf_matrix[n,L,S]: published confidence matrix (required; it doubles as the sim buffer).
  * Outputs have capacity n*L: b_ids,i_ids,j_ids (int64), mconf, mkpts0_c/mkpts1_c [.,2] (x,y);
  * counts[n+1] (int32): matches per pair, then the total M (read it after synchronising). */
-int pope_dense_match_f32(const float* feat0, const float* feat1, int n, int L, int S, int C,
+int pope_dense_match_f32(const float* feat0, long long stride0, const float* feat1, long long stride1,
+                         int n, int L, int S, int C,
                          int h0, int w0, int h1, int w1, float thr, int border_rm, float temperature,
                          float scale, float* conf_matrix, long long* b_ids, long long* i_ids,
                          long long* j_ids, float* mconf, float* mkpts0_c, float* mkpts1_c, int* counts,

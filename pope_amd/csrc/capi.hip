@@ -148,8 +148,8 @@ size_t pope_dense_match_workspace_bytes(int n, int L, int S) {
     return 5 * nl + 3 * ns;  // row_max,row_sum,conf_rowmax,row_j,row_conf | col_max,col_sum,conf_colmax
 }
 
-int pope_dense_match_f32(const float* feat0, const float* feat1, int n, int L, int S, int C, int h0, int w0, int h1,
-                         int w1, float thr, int border_rm, float temperature, float scale, float* conf_matrix,
+int pope_dense_match_f32(const float* feat0, long long stride0, const float* feat1, long long stride1, int n, int L,
+                         int S, int C, int h0, int w0, int h1, int w1, float thr, int border_rm, float temperature, float scale, float* conf_matrix,
                          long long* b_ids, long long* i_ids, long long* j_ids, float* mconf, float* mkpts0_c,
                          float* mkpts1_c, int* counts, void* workspace, size_t workspace_bytes, void* stream) {
     if (!feat0 || !feat1 || !conf_matrix || !b_ids || !i_ids || !j_ids || !mconf || !mkpts0_c || !mkpts1_c ||
@@ -161,6 +161,7 @@ int pope_dense_match_f32(const float* feat0, const float* feat1, int n, int L, i
     MatchParams p = {};
     p.feat0 = feat0; p.feat1 = feat1;
     p.n = n; p.L = L; p.S = S; p.C = C;
+    p.bs0 = stride0; p.bs1 = stride1;
     p.h0 = h0; p.w0 = w0; p.h1 = h1; p.w1 = w1;
     p.thr = thr; p.temperature = temperature; p.border = border_rm; p.scale = scale;
     p.sim = conf_matrix;

@@ -39,6 +39,7 @@ struct MatchParams {
     const float* feat0;  // [n, L, C]
     const float* feat1;  // [n, S, C]
     int n, L, S, C;
+    long long bs0, bs1;  // elements between consecutive pairs in feat0 / feat1 (>= L*C, S*C)
     int h0, w0, h1, w1;  // coarse grids (L = h0*w0, S = h1*w1)
     float thr, temperature;
     int border;

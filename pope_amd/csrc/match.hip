@@ -28,8 +28,8 @@ __global__ __launch_bounds__(THREADS, 2) void sim_kernel(const MatchParams p, fl
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int pair = blockIdx.y;
-    const float* f0 = p.feat0 + size_t(pair) * p.L * p.C;
-    const float* f1 = p.feat1 + size_t(pair) * p.S * p.C;
+    const float* f0 = p.feat0 + size_t(pair) * p.bs0;
+    const float* f1 = p.feat1 + size_t(pair) * p.bs1;
     const float norm = sqrtf(float(p.C));  // feat / C**.5 as an fp32 division (coarse_matching.py:109)
 
     f32x16 acc[2][2];
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const MatchParams p) {
 int pope_launch_dense_match_f32(const MatchParams& p, hipStream_t stream) {
     if (p.n <= 0 || p.L <= 0 || p.S <= 0 || p.C <= 0 || (p.C & 3) || p.n > 65535) return POPE_ERR_ARG;
     if (p.L != p.h0 * p.w0 || p.S != p.h1 * p.w1) return POPE_ERR_ARG;
+    if (p.bs0 < (long long)p.L * p.C || p.bs1 < (long long)p.S * p.C || (p.bs0 & 3) || (p.bs1 & 3)) return POPE_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(p.feat0) & 15) || (reinterpret_cast<uintptr_t>(p.feat1) & 15)) return POPE_ERR_ARG;
     static bool attr_set = false;
     if (!attr_set) {

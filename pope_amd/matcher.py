@@ -26,6 +26,14 @@ default_cfg = {
 }
 
 
+def _rows_contiguous(f):
+    """Accept [n, L, C] views whose rows are dense (e.g. x_norm[:, 1:]) without copying."""
+    if f.stride(2) == 1 and f.stride(1) == f.shape[2] and f.stride(0) >= f.shape[1] * f.shape[2] \
+            and f.stride(0) % 4 == 0 and f.data_ptr() % 16 == 0:
+        return f
+    return f.contiguous()
+
+
 @torch.no_grad()
 def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, temperature=0.1):
     """All-pairs similarity -> dual softmax -> threshold/border/mutual-NN -> ordered matches.
@@ -38,7 +46,7 @@ def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, tempera
     require_cuda(feat1, "dense_match")
     if feat0.dtype != torch.float32 or feat1.dtype != torch.float32:
         raise TypeError("dense_match expects float32 features")
-    feat0, feat1 = feat0.contiguous(), feat1.contiguous()
+    feat0, feat1 = _rows_contiguous(feat0), _rows_contiguous(feat1)
     n, L, Cc = feat0.shape
     S = feat1.shape[1]
     h0, w0 = int(hw0_c[0]), int(hw0_c[1])
@@ -58,7 +66,8 @@ def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, tempera
     mk1 = torch.empty(cap, 2, dtype=torch.float32, device=dev)
     counts = torch.empty(n + 1, dtype=torch.int32, device=dev)
     scale = hw0_i[0] / hw0_c[0]  # coarse_matching.py:242 (heights only)
-    check(lib.pope_dense_match_f32(ptr(feat0), ptr(feat1), n, L, S, Cc, h0, w0, h1, w1, float(thr), int(border_rm),
+    check(lib.pope_dense_match_f32(C.c_void_p(feat0.data_ptr()), feat0.stride(0), C.c_void_p(feat1.data_ptr()),
+                                   feat1.stride(0), n, L, S, Cc, h0, w0, h1, w1, float(thr), int(border_rm),
                                    float(temperature), float(scale), ptr(conf), ptr(b_ids), ptr(i_ids), ptr(j_ids),
                                    ptr(mconf), ptr(mk0), ptr(mk1), ptr(counts), C.c_void_p(ws.data_ptr()), ws_bytes,
                                    stream_of(dev)), "pope_dense_match_f32")
