@@ -1,4 +1,4 @@
-// Shared 128x128x32 fp32-MFMA tile mainloop (see gemm_f32.hip for the design notes).
+// Shared 128x128x32 fp32-MFMA tile mainloop + coalesced epilogue (see gemm_f32.hip for the design).
 #pragma once
 #include "common.h"
 
@@ -6,16 +6,24 @@ namespace gemm_core {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDS_ST = 36;
 constexpr int THREADS = 256;
-constexpr size_t LDS_BYTES = size_t(2) * (BM + BN) * LDS_ST * sizeof(float);
+// ONE LDS stage (A and W tiles of one K-step): 36.9 KB -> three workgroups per CU (VGPR-limited),
+// i.e. three waves per SIMD from three independent workgroups: their barrier, LDS-turnaround
+// and epilogue bubbles interleave instead of lining up (measured with two lock-stepped
+// workgroups per CU and double-buffered LDS: MFMA pipe busy only 60-67 %).
+constexpr size_t LDS_BYTES = size_t(BM + BN) * LDS_ST * sizeof(float);
+constexpr int EPI_ST = 68;  // epilogue staging row (floats): 17 x 16 B, conflict-free b128 rows
+static_assert(size_t(4) * 32 * EPI_ST * sizeof(float) <= LDS_BYTES, "epilogue staging must fit the K-step stage");
 
-// acc[mi][ni] += A_tile . W_tile^T over K.  `la(row, k)` / `lw(row, k)` return the four
-// K-contiguous floats at (tile row `row` in [0,128), absolute k) or zeros outside the operand.
-// Register-staged double buffering: the global loads of K-tile t+1 are issued before the 64
-// MFMAs of K-tile t and written to the other LDS buffer after them; one barrier per K-tile.
+// acc = (A_tile . W_tile^T)^T over K, i.e. acc[mi][ni] holds C^T: register rows run over n,
+// the lane column over m — so a lane owns 4 consecutive output columns per register quad and the
+// epilogue can move 16-byte pieces.  `la(row, k)` / `lw(row, k)` return the four K-contiguous
+// floats at (tile row in [0,128), absolute k) or zeros outside the operand.
+// Register prefetch: the global loads of K-step t+1 are issued right after the LDS stage of
+// K-step t is published and complete under its 64 MFMAs.
 template <class LoadA, class LoadW>
 __device__ __forceinline__ void mainloop(LoadA la, LoadW lw, int K, float* smem, f32x16 (&acc)[2][2]) {
-    float* As = smem;                    // [2][BM][LDS_ST]
-    float* Ws = smem + 2 * BM * LDS_ST;  // [2][BN][LDS_ST]
+    float* As = smem;                // [BM][LDS_ST]
+    float* Ws = smem + BM * LDS_ST;  // [BN][LDS_ST]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
     const int srow = tid >> 3, scol = (tid & 7) * 4;
@@ -35,23 +43,19 @@ __device__ __forceinline__ void mainloop(LoadA la, LoadW lw, int K, float* smem,
             rw[i] = lw(srow + 32 * i, k0 + scol);
         }
     };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&As[(buf * BM + srow + 32 * i) * LDS_ST + scol]) = ra[i];
-            *reinterpret_cast<f32x4*>(&Ws[(buf * BN + srow + 32 * i) * LDS_ST + scol]) = rw[i];
-        }
-    };
-
     const int nk = (K + BK - 1) / BK;
     load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    const float* a_base = &As[(wm * 64 + r) * LDS_ST + 4 * h];
+    const float* w_base = &Ws[(wn * 64 + r) * LDS_ST + 4 * h];
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        if (kt) __syncthreads();  // every wave is done reading the previous stage
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * LDS_ST + scol]) = ra[i];
+            *reinterpret_cast<f32x4*>(&Ws[(srow + 32 * i) * LDS_ST + scol]) = rw[i];
+        }
+        __syncthreads();
         if (kt + 1 < nk) load_tile((kt + 1) * BK);
-        const float* a_base = &As[(cur * BM + wm * 64 + r) * LDS_ST + 4 * h];
-        const float* w_base = &Ws[(cur * BN + wn * 64 + r) * LDS_ST + 4 * h];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 a[2], b[2];
@@ -66,25 +70,42 @@ __device__ __forceinline__ void mainloop(LoadA la, LoadW lw, int K, float* smem,
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = mfma_32x32x2(a[mi][s], b[ni][s], acc[mi][ni]);
+                        acc[mi][ni] = mfma_32x32x2(b[ni][s], a[mi][s], acc[mi][ni]);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
     }
 }
 
-// Visit every accumulator element of this lane: f(row_in_tile, col_in_tile, value).
+// Coalesced epilogue: each wave transposes its 64x64 sub-tile through a private 32x68-float LDS
+// region (two passes of 32 rows; wave-local, no workgroup barrier after the initial one) and
+// calls f(row_in_tile, col_in_tile, v) with v = four consecutive output columns; the 16 lanes
+// sharing a row cover 256 contiguous bytes, so f's loads/stores are whole 256-B row segments
+// and a wave issues 16 wide stores instead of 64 dword stores.
 template <class F>
-__device__ __forceinline__ void for_each_output(const f32x16 (&acc)[2][2], F f) {
+__device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[2][2], float* smem, F f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    __syncthreads();  // all waves have finished reading the last K-step stage
+    float* E = smem + wave * 32 * EPI_ST;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                f(wm * 64 + mi * 32 + mfma32_row(i, h), wn * 64 + ni * 32 + r, acc[mi][ni][i]);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g4 + e];
+                *reinterpret_cast<f32x4*>(&E[r * EPI_ST + ni * 32 + 8 * g4 + 4 * h]) = v;
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int lr = (lane >> 4) + 4 * i, c4 = (lane & 15) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&E[lr * EPI_ST + c4]);
+            f(wm * 64 + mi * 32 + lr, wn * 64 + c4, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 }  // namespace gemm_core

@@ -6,10 +6,10 @@
 // (patch_embed.py:69-82) fused with "+cls, +pos_embed" (vision_transformer.py:191-200).
 //
 // Tiling: 128x128 block tile, BK=32, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles,
-// v_mfma_f32_32x32x2_f32 (exact f32 fma chain).  Both operands are K-contiguous, so both are
-// staged identically: global -> registers (prefetch of tile t+1 issued before the MFMAs of
-// tile t) -> LDS rows padded to 36 floats (ds_read_b128 conflict-free: 9*r mod 16 is a
-// bijection on a 16-lane group).  The k order inside an 8-wide group is permuted
+// v_mfma_f32_32x32x2_f32 (exact f32 fma chain), three workgroups per CU.  Both operands are
+// K-contiguous, so both are staged identically: global -> registers (prefetch of K-step t+1
+// in flight under the MFMAs of K-step t) -> one LDS stage, rows padded to 36 floats
+// (ds_read_b128 conflict-free: 9*r mod 16 is a bijection on a 16-lane group).  The k order inside an 8-wide group is permuted
 // (lane half h takes k = 8j+4h+s at step s) so that one ds_read_b128 feeds four MFMAs; A and
 // W use the same permutation, so the sum is over the same products.
 #include "gemm_core.h"
@@ -58,7 +58,7 @@ __device__ __forceinline__ f32x4 load_w(const GemmParams& g, int row, int k) {
 }
 
 template <int EPI, bool PATCH>
-__global__ __launch_bounds__(THREADS, 2) void gemm_nt_f32_kernel(const GemmParams g) {
+__global__ __launch_bounds__(THREADS, 3) void gemm_nt_f32_kernel(const GemmParams g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tiles_n = (g.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -68,21 +68,27 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f32_kernel(const GemmParam
     mainloop([&](int row, int k) { return load_a<PATCH>(g, m0 + row, k); },
              [&](int row, int k) { return load_w(g, n0 + row, k); }, g.K, smem, acc);
 
-    // Epilogue straight from the accumulators: each register is one output row segment of 32
-    // consecutive columns per lane half (128 B per half-wave store).
-    for_each_output(acc, [&](int tr, int tc, float v) {
+    // Coalesced epilogue (gemm_core::epilogue_rows): four consecutive output columns per call.
+    epilogue_rows(acc, smem, [&](int tr, int tc, f32x4 v) {
         const int row = m0 + tr, col = n0 + tc;
-        if (row >= g.M || col >= g.N) return;
+        if (row >= g.M || col >= g.N) return;  // N % 4 == 0: a quad is inside or outside as a whole
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI != EPI_POSB)
+            if (g.bias) bias = *reinterpret_cast<const f32x4*>(g.bias + col);
         if constexpr (EPI == EPI_BIAS) {
-            v = v + (g.bias ? g.bias[col] : 0.f);
+            v = v + bias;
         } else if constexpr (EPI == EPI_BIAS_GELU) {
-            v = gelu_erf(v + (g.bias ? g.bias[col] : 0.f));
+            v = v + bias;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         } else if constexpr (EPI == EPI_BIAS_LS_RES) {
-            v = g.res[size_t(row) * g.ldres + col] + (v + (g.bias ? g.bias[col] : 0.f)) * g.gamma[col];
+            const f32x4 gamma = *reinterpret_cast<const f32x4*>(g.gamma + col);
+            const f32x4 res = *reinterpret_cast<const f32x4*>(g.res + size_t(row) * g.ldres + col);
+            v = res + (v + bias) * gamma;
         } else {  // EPI_POSB: + (pos_embed + conv bias | cls) table indexed by token
-            v = v + g.posb[size_t(row % g.ntok) * g.N + col];
+            v = v + *reinterpret_cast<const f32x4*>(g.posb + size_t(row % g.ntok) * g.N + col);
         }
-        g.C[size_t(row) * g.ldc + col] = v;
+        *reinterpret_cast<f32x4*>(g.C + size_t(row) * g.ldc + col) = v;
     });
 }
 
@@ -104,7 +110,8 @@ int launch(const GemmParams& g, hipStream_t stream) {
 }  // namespace
 
 int pope_launch_gemm_nt_f32(const GemmParams& g, hipStream_t stream) {
-    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K & 3)) return POPE_ERR_ARG;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K & 3) || (g.N & 3) || (g.ldc & 3)) return POPE_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(g.C) & 15) return POPE_ERR_ARG;
     if (g.epilogue != EPI_POSB && ((g.lda & 3) || (reinterpret_cast<uintptr_t>(g.A) & 15))) return POPE_ERR_ARG;
     if ((g.ldw & 3) || (reinterpret_cast<uintptr_t>(g.W) & 15)) return POPE_ERR_ARG;
     switch (g.epilogue) {

@@ -22,7 +22,7 @@ namespace {
 
 using namespace gemm_core;
 
-__global__ __launch_bounds__(THREADS, 2) void sim_kernel(const MatchParams p, float inv_unused) {
+__global__ __launch_bounds__(THREADS, 3) void sim_kernel(const MatchParams p, float inv_unused) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tiles_n = (p.S + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -48,9 +48,20 @@ __global__ __launch_bounds__(THREADS, 2) void sim_kernel(const MatchParams p, fl
 
     float* sim = p.sim + size_t(pair) * p.L * p.S;
     const float temp = p.temperature;
-    for_each_output(acc, [&](int tr, int tc, float v) {
+    const bool even = !(p.S & 1);  // row starts are 8-byte aligned -> two float2 stores per quad
+    epilogue_rows(acc, smem, [&](int tr, int tc, f32x4 v) {
         const int row = m0 + tr, col = n0 + tc;
-        if (row < p.L && col < p.S) sim[size_t(row) * p.S + col] = v / temp;
+        if (row >= p.L || col >= p.S) return;
+        float* o = sim + size_t(row) * p.S + col;
+        v = v / temp;
+        if (even && col + 3 < p.S) {
+            *reinterpret_cast<f32x2*>(o) = f32x2{v[0], v[1]};
+            *reinterpret_cast<f32x2*>(o + 2) = f32x2{v[2], v[3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < p.S) o[e] = v[e];
+        }
     });
 }
 
