@@ -20,13 +20,18 @@ constexpr int HD = 64;    // head dim (all DINOv2 archs)
 constexpr int KT = 64;    // keys per LDS tile
 constexpr int QB = 128;   // queries per block (4 waves x 32)
 constexpr int ST = 68;    // padded LDS row (floats): 17 x 16 B -> ds_read_b128 conflict-free
-constexpr size_t ATTN_LDS_BYTES = size_t(4) * KT * ST * sizeof(float);  // K[2] + V[2]
+// ONE K and ONE V stage (34.8 KB): three workgroups per CU, so every SIMD hosts three waves of
+// independent workgroups whose softmax (VALU) and barrier phases fall under each other's MFMAs.
+constexpr size_t ATTN_LDS_BYTES = size_t(2) * KT * ST * sizeof(float);
 
-__global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+// ABLATE is 0 in the product; the lab harness (scripts/attn_lab.hip) instantiates timing-only
+// variants: bit0 = no softmax VALU, bit1 = no P.V MFMAs, bit2 = no Q.K^T MFMAs.
+template <int ABLATE>
+__global__ __launch_bounds__(256, 3) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                            int N, int heads) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                // [2][KT][ST]
-    float* Vs = smem + 2 * KT * ST;  // [2][KT][ST]
+    float* Ks = smem;            // [KT][ST]
+    float* Vs = smem + KT * ST;  // [KT][ST]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -63,11 +68,11 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
             rv[i] = zv;
         }
     };
-    auto store_kv = [&](int buf) {
+    auto store_kv = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&Ks[(buf * KT + srow + 16 * i) * ST + scol]) = rk[i];
-            *reinterpret_cast<f32x4*>(&Vs[(buf * KT + srow + 16 * i) * ST + scol]) = rv[i];
+            *reinterpret_cast<f32x4*>(&Ks[(srow + 16 * i) * ST + scol]) = rk[i];
+            *reinterpret_cast<f32x4*>(&Vs[(srow + 16 * i) * ST + scol]) = rv[i];
         }
     };
 
@@ -78,18 +83,18 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
 
     const int nkt = (N + KT - 1) / KT;
     load_kv(0);
-    store_kv(0);
-    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) load_kv(kt + 1);
+        if (kt) __syncthreads();  // every wave is done with the previous K/V stage
+        store_kv();
+        __syncthreads();
+        if (kt + 1 < nkt) load_kv(kt + 1);  // in flight under this tile's 128 MFMAs
 
         f32x16 s0, s1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
-        const float* kb = &Ks[(cur * KT + r) * ST + 4 * h];
+        const float* kb = &Ks[r * ST + 4 * h];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < ((ABLATE & 4) ? 1 : 8); ++j) {
             const f32x4 k0 = *reinterpret_cast<const f32x4*>(kb + 8 * j);
             const f32x4 k1 = *reinterpret_cast<const f32x4*>(kb + 32 * ST + 8 * j);
 #pragma unroll
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
                 if (key + 32 >= N) s1[i] = -INFINITY;
             }
         }
+        if constexpr (!(ABLATE & 1)) {
         float mt = fmaxf(s0[0], s1[0]);
 #pragma unroll
         for (int i = 1; i < 16; ++i) mt = fmaxf(mt, fmaxf(s0[i], s1[i]));
@@ -123,8 +129,15 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
         l_run = l_run * alpha + ls;
         o0 *= alpha;
         o1 *= alpha;
+        } else {
+            l_run = 1.f;
+        }
 
-        const float* vb = &Vs[(cur * KT) * ST + r];
+        const float* vb = &Vs[r];
+        if constexpr (ABLATE & 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] += s0[i]; o1[i] += s1[i]; }
+        } else {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int row = mfma32_row(t, h);
@@ -137,9 +150,9 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
             o0 = mfma_32x32x2(vb[row * ST], s1[t], o0);
             o1 = mfma_32x32x2(vb[row * ST + 32], s1[t], o1);
         }
-        if (kt + 1 < nkt) store_kv(cur ^ 1);
-        __syncthreads();
+        }
     }
+    __syncthreads();  // the stage is free: reuse it for the O^T transpose
 
     // Normalise, transpose O^T through LDS (K buffers are free after the final barrier; each
     // wave touches only its own 32 rows) and store whole 256-B head rows.
@@ -171,12 +184,12 @@ int pope_launch_attention_f32(const float* qkv, float* out, int B, int N, int he
     if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return POPE_ERR_ARG;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_kernel<0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(ATTN_LDS_BYTES)) != hipSuccess)
             return POPE_ERR_LAUNCH;
         attr_set = true;
     }
     const dim3 grid((N + QB - 1) / QB, heads, B);
-    hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), ATTN_LDS_BYTES, stream, qkv, out, N, heads);
+    hipLaunchKernelGGL(attn_f32_kernel<0>, grid, dim3(256), ATTN_LDS_BYTES, stream, qkv, out, N, heads);
     return pope_check_launch();
 }
