@@ -14,14 +14,50 @@ constexpr size_t LDS_BYTES = size_t(BM + BN) * LDS_ST * sizeof(float);
 constexpr int EPI_ST = 68;  // epilogue staging row (floats): 17 x 16 B, conflict-free b128 rows
 static_assert(size_t(4) * 32 * EPI_ST * sizeof(float) <= LDS_BYTES, "epilogue staging must fit the K-step stage");
 
+// ---- operand loaders -------------------------------------------------------------------------
+// A loader serves this thread's four staging pieces of a K-step: piece i = the four K-contiguous
+// floats at tile row (tid>>3) + 32*i, columns k0 + (tid&7)*4 .. +3; zeros outside the operand.
+
+// Dense row-major operand [rows, ld] with ld == K-extent % 32 == 0, < 4 GiB: one
+// `buffer_load_dwordx4 ... offen` per piece — per-piece byte offset in a loop-invariant VGPR, the
+// K-step offset in an SGPR, rows past the end zero-filled by the buffer bounds check.  No
+// address arithmetic, no exec-mask branches in the K loop (the plain-pointer loader's guards
+// cost ~10 % of the GEMM: lab ablation "noload").
+struct BufferLoader {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned voff[4];
+    __device__ __forceinline__ BufferLoader(const float* base, int rows, int ld, int row0) {
+        // base / rows / ld are kernel arguments (wave-uniform): the descriptor stays in SGPRs
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, unsigned(rows) * unsigned(ld) * 4u, 0x00020000);
+        const int srow = threadIdx.x >> 3, scol = (threadIdx.x & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) voff[i] = (unsigned(row0 + srow + 32 * i) * unsigned(ld) + scol) * 4u;
+    }
+    __device__ __forceinline__ f32x4 load(int i, int k0) const {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], k0 * 4, 0));
+    }
+};
+
+// Generic loader: f(tile_row, k) -> four floats (guards, gathers and prescales live in f).
+template <class F>
+struct FnLoader {
+    F f;
+    __device__ __forceinline__ f32x4 load(int i, int k0) const {
+        return f((threadIdx.x >> 3) + 32 * i, k0 + (threadIdx.x & 7) * 4);
+    }
+};
+template <class F>
+__device__ __forceinline__ FnLoader<F> fn_loader(F f) { return FnLoader<F>{f}; }
+
 // acc = (A_tile . W_tile^T)^T over K, i.e. acc[mi][ni] holds C^T: register rows run over n,
 // the lane column over m — so a lane owns 4 consecutive output columns per register quad and the
-// epilogue can move 16-byte pieces.  `la(row, k)` / `lw(row, k)` return the four K-contiguous
-// floats at (tile row in [0,128), absolute k) or zeros outside the operand.
+// epilogue can move 16-byte pieces.
 // Register prefetch: the global loads of K-step t+1 are issued right after the LDS stage of
 // K-step t is published and complete under its 64 MFMAs.
-template <class LoadA, class LoadW>
-__device__ __forceinline__ void mainloop(LoadA la, LoadW lw, int K, float* smem, f32x16 (&acc)[2][2]) {
+// LAB is 0 in the product; scripts/gemm_lab.hip instantiates timing-only ablations:
+// bit0 = no global loads after the first K-step, bit1 = no LDS restaging/barriers after the first.
+template <int LAB = 0, class LoaderA, class LoaderW>
+__device__ __forceinline__ void mainloop(const LoaderA& la, const LoaderW& lw, int K, float* smem, f32x16 (&acc)[2][2]) {
     float* As = smem;                // [BM][LDS_ST]
     float* Ws = smem + BM * LDS_ST;  // [BN][LDS_ST]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -39,8 +75,8 @@ __device__ __forceinline__ void mainloop(LoadA la, LoadW lw, int K, float* smem,
     auto load_tile = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = la(srow + 32 * i, k0 + scol);
-            rw[i] = lw(srow + 32 * i, k0 + scol);
+            ra[i] = la.load(i, k0);
+            rw[i] = lw.load(i, k0);
         }
     };
     const int nk = (K + BK - 1) / BK;
@@ -48,14 +84,16 @@ __device__ __forceinline__ void mainloop(LoadA la, LoadW lw, int K, float* smem,
     const float* a_base = &As[(wm * 64 + r) * LDS_ST + 4 * h];
     const float* w_base = &Ws[(wn * 64 + r) * LDS_ST + 4 * h];
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt) __syncthreads();  // every wave is done reading the previous stage
+        if (!(LAB & 2) || kt == 0) {
+            if (kt) __syncthreads();  // every wave is done reading the previous stage
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * LDS_ST + scol]) = ra[i];
-            *reinterpret_cast<f32x4*>(&Ws[(srow + 32 * i) * LDS_ST + scol]) = rw[i];
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * LDS_ST + scol]) = ra[i];
+                *reinterpret_cast<f32x4*>(&Ws[(srow + 32 * i) * LDS_ST + scol]) = rw[i];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        if (!(LAB & 1) && kt + 1 < nk) load_tile((kt + 1) * BK);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 a[2], b[2];

@@ -57,7 +57,9 @@ __device__ __forceinline__ f32x4 load_w(const GemmParams& g, int row, int k) {
     return *reinterpret_cast<const f32x4*>(g.W + size_t(row) * g.ldw + k);
 }
 
-template <int EPI, bool PATCH>
+enum { LOAD_GENERIC = 0, LOAD_BUFFER = 1, LOAD_PATCH = 2 };
+
+template <int EPI, int LOADER>
 __global__ __launch_bounds__(THREADS, 3) void gemm_nt_f32_kernel(const GemmParams g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tiles_n = (g.N + BN - 1) / BN;
@@ -65,8 +67,12 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_nt_f32_kernel(const GemmParam
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
 
     f32x16 acc[2][2];
-    mainloop([&](int row, int k) { return load_a<PATCH>(g, m0 + row, k); },
-             [&](int row, int k) { return load_w(g, n0 + row, k); }, g.K, smem, acc);
+    if constexpr (LOADER == LOAD_BUFFER) {
+        mainloop(BufferLoader(g.A, g.M, g.lda, m0), BufferLoader(g.W, g.N, g.ldw, n0), g.K, smem, acc);
+    } else {
+        mainloop(fn_loader([&](int row, int k) { return load_a<LOADER == LOAD_PATCH>(g, m0 + row, k); }),
+                 fn_loader([&](int row, int k) { return load_w(g, n0 + row, k); }), g.K, smem, acc);
+    }
 
     // Coalesced epilogue (gemm_core::epilogue_rows): four consecutive output columns per call.
     epilogue_rows(acc, smem, [&](int tr, int tc, f32x4 v) {
@@ -92,19 +98,19 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_nt_f32_kernel(const GemmParam
     });
 }
 
-template <int EPI, bool PATCH>
+template <int EPI, int LOADER>
 int launch(const GemmParams& g, hipStream_t stream) {
-    static bool attr_set = false;  // >64 KB dynamic LDS needs the opt-in once per kernel
-    auto kern = gemm_nt_f32_kernel<EPI, PATCH>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                int(LDS_BYTES)) != hipSuccess)
-            return POPE_ERR_LAUNCH;
-        attr_set = true;
-    }
-    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS), LDS_BYTES, stream, g);
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<EPI, LOADER>), dim3(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN)),
+                       dim3(THREADS), LDS_BYTES, stream, g);
     return pope_check_launch();
+}
+
+template <int EPI>
+int launch_linear(const GemmParams& g, hipStream_t stream) {
+    // fast path: K-steps never straddle a row end and every byte offset fits the 32-bit buffer offset
+    const bool fast = (g.K % BK) == 0 && size_t(g.M + BM) * g.lda * 4 < (size_t(1) << 32) &&
+                      size_t(g.N + BN) * g.ldw * 4 < (size_t(1) << 32);
+    return fast ? launch<EPI, LOAD_BUFFER>(g, stream) : launch<EPI, LOAD_GENERIC>(g, stream);
 }
 
 }  // namespace
@@ -115,14 +121,14 @@ int pope_launch_gemm_nt_f32(const GemmParams& g, hipStream_t stream) {
     if (g.epilogue != EPI_POSB && ((g.lda & 3) || (reinterpret_cast<uintptr_t>(g.A) & 15))) return POPE_ERR_ARG;
     if ((g.ldw & 3) || (reinterpret_cast<uintptr_t>(g.W) & 15)) return POPE_ERR_ARG;
     switch (g.epilogue) {
-        case EPI_BIAS: return launch<EPI_BIAS, false>(g, stream);
-        case EPI_BIAS_GELU: return launch<EPI_BIAS_GELU, false>(g, stream);
+        case EPI_BIAS: return launch_linear<EPI_BIAS>(g, stream);
+        case EPI_BIAS_GELU: return launch_linear<EPI_BIAS_GELU>(g, stream);
         case EPI_BIAS_LS_RES:
             if (!g.gamma || !g.res) return POPE_ERR_ARG;
-            return launch<EPI_BIAS_LS_RES, false>(g, stream);
+            return launch_linear<EPI_BIAS_LS_RES>(g, stream);
         case EPI_POSB:
             if (!g.posb || g.ntok <= 0 || g.patch <= 0) return POPE_ERR_ARG;
-            return launch<EPI_POSB, true>(g, stream);
+            return launch<EPI_POSB, LOAD_PATCH>(g, stream);
     }
     return POPE_ERR_ARG;
 }

@@ -33,18 +33,17 @@ __global__ __launch_bounds__(THREADS, 3) void sim_kernel(const MatchParams p, fl
     const float norm = sqrtf(float(p.C));  // feat / C**.5 as an fp32 division (coarse_matching.py:109)
 
     f32x16 acc[2][2];
-    mainloop(
-        [&](int row, int k) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m0 + row < p.L && k < p.C) v = *reinterpret_cast<const f32x4*>(f0 + size_t(m0 + row) * p.C + k) / norm;
-            return v;
-        },
-        [&](int row, int k) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n0 + row < p.S && k < p.C) v = *reinterpret_cast<const f32x4*>(f1 + size_t(n0 + row) * p.C + k) / norm;
-            return v;
-        },
-        p.C, smem, acc);
+    mainloop(fn_loader([&](int row, int k) {
+                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                 if (m0 + row < p.L && k < p.C) v = *reinterpret_cast<const f32x4*>(f0 + size_t(m0 + row) * p.C + k) / norm;
+                 return v;
+             }),
+             fn_loader([&](int row, int k) {
+                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                 if (n0 + row < p.S && k < p.C) v = *reinterpret_cast<const f32x4*>(f1 + size_t(n0 + row) * p.C + k) / norm;
+                 return v;
+             }),
+             p.C, smem, acc);
 
     float* sim = p.sim + size_t(pair) * p.L * p.S;
     const float temp = p.temperature;
@@ -234,13 +233,6 @@ int pope_launch_dense_match_f32(const MatchParams& p, hipStream_t stream) {
     if (p.L != p.h0 * p.w0 || p.S != p.h1 * p.w1) return POPE_ERR_ARG;
     if (p.bs0 < (long long)p.L * p.C || p.bs1 < (long long)p.S * p.C || (p.bs0 & 3) || (p.bs1 & 3)) return POPE_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(p.feat0) & 15) || (reinterpret_cast<uintptr_t>(p.feat1) & 15)) return POPE_ERR_ARG;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(sim_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                int(LDS_BYTES)) != hipSuccess)
-            return POPE_ERR_LAUNCH;
-        attr_set = true;
-    }
     const int tiles = ((p.L + BM - 1) / BM) * ((p.S + BN - 1) / BN);
     hipLaunchKernelGGL(sim_kernel, dim3(tiles, p.n), dim3(THREADS), LDS_BYTES, stream, p, 0.f);
     const dim3 rows((p.L + 3) / 4, p.n), cols((p.S + 63) / 64, p.n);
