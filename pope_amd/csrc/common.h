@@ -42,6 +42,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return base + (bid >> 3);
 }
 
+// Number of CUs of the current device (cached; 256 on MI355X).  Host-side query, no sync.
+static inline int pope_cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
 static inline int pope_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? POPE_OK : POPE_ERR_LAUNCH;

@@ -52,12 +52,17 @@ __device__ __forceinline__ FnLoader<F> fn_loader(F f) { return FnLoader<F>{f}; }
 // acc = (A_tile . W_tile^T)^T over K, i.e. acc[mi][ni] holds C^T: register rows run over n,
 // the lane column over m — so a lane owns 4 consecutive output columns per register quad and the
 // epilogue can move 16-byte pieces.
-// Register prefetch: the global loads of K-step t+1 are issued right after the LDS stage of
-// K-step t is published and complete under its 64 MFMAs.
+// Register prefetch: on entry ra/rw hold K-step 0 of this tile; the global loads of K-step t+1
+// are issued right after the LDS stage of K-step t is published and complete under its 64 MFMAs.
+// During the LAST K-step the loads of K-step 0 of the workgroup's NEXT tile are issued (nla/nlw,
+// if has_next) so that a persistent workgroup streams across tile seams: the epilogue's stores
+// drain under the next tile's MFMAs instead of holding the CU slot until HBM has taken them.
 // LAB is 0 in the product; scripts/gemm_lab.hip instantiates timing-only ablations:
 // bit0 = no global loads after the first K-step, bit1 = no LDS restaging/barriers after the first.
 template <int LAB = 0, class LoaderA, class LoaderW>
-__device__ __forceinline__ void mainloop(const LoaderA& la, const LoaderW& lw, int K, float* smem, f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void mainloop_prefetched(const LoaderA& la, const LoaderW& lw, const LoaderA& nla,
+                                                    const LoaderW& nlw, bool has_next, int K, float* smem,
+                                                    f32x16 (&acc)[2][2], f32x4 (&ra)[4], f32x4 (&rw)[4]) {
     float* As = smem;                // [BM][LDS_ST]
     float* Ws = smem + BM * LDS_ST;  // [BN][LDS_ST]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,21 +76,12 @@ __device__ __forceinline__ void mainloop(const LoaderA& la, const LoaderW& lw, i
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-    f32x4 ra[4], rw[4];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = la.load(i, k0);
-            rw[i] = lw.load(i, k0);
-        }
-    };
     const int nk = (K + BK - 1) / BK;
-    load_tile(0);
     const float* a_base = &As[(wm * 64 + r) * LDS_ST + 4 * h];
     const float* w_base = &Ws[(wn * 64 + r) * LDS_ST + 4 * h];
     for (int kt = 0; kt < nk; ++kt) {
         if (!(LAB & 2) || kt == 0) {
-            if (kt) __syncthreads();  // every wave is done reading the previous stage
+            __syncthreads();  // every wave is done reading the previous stage / epilogue staging
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * LDS_ST + scol]) = ra[i];
@@ -93,7 +89,21 @@ __device__ __forceinline__ void mainloop(const LoaderA& la, const LoaderW& lw, i
             }
             __syncthreads();
         }
-        if (!(LAB & 1) && kt + 1 < nk) load_tile((kt + 1) * BK);
+        if (!(LAB & 1)) {
+            if (kt + 1 < nk) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ra[i] = la.load(i, (kt + 1) * BK);
+                    rw[i] = lw.load(i, (kt + 1) * BK);
+                }
+            } else if (has_next) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ra[i] = nla.load(i, 0);
+                    rw[i] = nlw.load(i, 0);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 a[2], b[2];
@@ -111,6 +121,18 @@ __device__ __forceinline__ void mainloop(const LoaderA& la, const LoaderW& lw, i
                         acc[mi][ni] = mfma_32x32x2(b[ni][s], a[mi][s], acc[mi][ni]);
         }
     }
+}
+
+// One tile, no cross-tile prefetch.
+template <int LAB = 0, class LoaderA, class LoaderW>
+__device__ __forceinline__ void mainloop(const LoaderA& la, const LoaderW& lw, int K, float* smem, f32x16 (&acc)[2][2]) {
+    f32x4 ra[4], rw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = la.load(i, 0);
+        rw[i] = lw.load(i, 0);
+    }
+    mainloop_prefetched<LAB>(la, lw, la, lw, false, K, smem, acc, ra, rw);
 }
 
 // Coalesced epilogue: each wave transposes its 64x64 sub-tile through a private 32x68-float LDS

@@ -57,23 +57,8 @@ __device__ __forceinline__ f32x4 load_w(const GemmParams& g, int row, int k) {
     return *reinterpret_cast<const f32x4*>(g.W + size_t(row) * g.ldw + k);
 }
 
-enum { LOAD_GENERIC = 0, LOAD_BUFFER = 1, LOAD_PATCH = 2 };
-
-template <int EPI, int LOADER>
-__global__ __launch_bounds__(THREADS, 3) void gemm_nt_f32_kernel(const GemmParams g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tiles_n = (g.N + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-
-    f32x16 acc[2][2];
-    if constexpr (LOADER == LOAD_BUFFER) {
-        mainloop(BufferLoader(g.A, g.M, g.lda, m0), BufferLoader(g.W, g.N, g.ldw, n0), g.K, smem, acc);
-    } else {
-        mainloop(fn_loader([&](int row, int k) { return load_a<LOADER == LOAD_PATCH>(g, m0 + row, k); }),
-                 fn_loader([&](int row, int k) { return load_w(g, n0 + row, k); }), g.K, smem, acc);
-    }
-
+template <int EPI>
+__device__ __forceinline__ void tile_epilogue(const GemmParams& g, int m0, int n0, const f32x16 (&acc)[2][2], float* smem) {
     // Coalesced epilogue (gemm_core::epilogue_rows): four consecutive output columns per call.
     epilogue_rows(acc, smem, [&](int tr, int tc, f32x4 v) {
         const int row = m0 + tr, col = n0 + tc;
@@ -98,6 +83,53 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_nt_f32_kernel(const GemmParam
     });
 }
 
+enum { LOAD_GENERIC = 0, LOAD_BUFFER = 1, LOAD_PATCH = 2 };
+
+// One tile per workgroup (generic pointer loader / im2col gather loader).
+template <int EPI, int LOADER>
+__global__ __launch_bounds__(THREADS, 3) void gemm_nt_f32_kernel(const GemmParams g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    f32x16 acc[2][2];
+    mainloop(fn_loader([&](int row, int k) { return load_a<LOADER == LOAD_PATCH>(g, m0 + row, k); }),
+             fn_loader([&](int row, int k) { return load_w(g, n0 + row, k); }), g.K, smem, acc);
+    tile_epilogue<EPI>(g, m0, n0, acc, smem);
+}
+
+// Persistent workgroups (3 per CU) streaming over tiles, buffer-load staging.  Logical workgroup
+// id = xcd_remap(blockIdx): XCD x walks tiles [round*grid + x*grid/8, ...), i.e. whole row panels
+// of A stay within one XCD's L2 in every round.
+template <int EPI>
+__global__ __launch_bounds__(THREADS, 3) void gemm_nt_f32_persistent_kernel(const GemmParams g, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int stride = gridDim.x;
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= n_tiles) return;
+    f32x4 ra[4], rw[4];
+    {
+        const BufferLoader la(g.A, g.M, g.lda, (tile / tiles_n) * BM), lw(g.W, g.N, g.ldw, (tile % tiles_n) * BN);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = la.load(i, 0);
+            rw[i] = lw.load(i, 0);
+        }
+    }
+    for (; tile < n_tiles; tile += stride) {
+        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+        const int nt = tile + stride;
+        const bool has_next = nt < n_tiles;
+        const int nm0 = has_next ? (nt / tiles_n) * BM : m0, nn0 = has_next ? (nt % tiles_n) * BN : n0;
+        f32x16 acc[2][2];
+        mainloop_prefetched(BufferLoader(g.A, g.M, g.lda, m0), BufferLoader(g.W, g.N, g.ldw, n0),
+                            BufferLoader(g.A, g.M, g.lda, nm0), BufferLoader(g.W, g.N, g.ldw, nn0), has_next, g.K, smem,
+                            acc, ra, rw);
+        tile_epilogue<EPI>(g, m0, n0, acc, smem);
+    }
+}
+
 template <int EPI, int LOADER>
 int launch(const GemmParams& g, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_nt_f32_kernel<EPI, LOADER>), dim3(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN)),
@@ -110,7 +142,12 @@ int launch_linear(const GemmParams& g, hipStream_t stream) {
     // fast path: K-steps never straddle a row end and every byte offset fits the 32-bit buffer offset
     const bool fast = (g.K % BK) == 0 && size_t(g.M + BM) * g.lda * 4 < (size_t(1) << 32) &&
                       size_t(g.N + BN) * g.ldw * 4 < (size_t(1) << 32);
-    return fast ? launch<EPI, LOAD_BUFFER>(g, stream) : launch<EPI, LOAD_GENERIC>(g, stream);
+    if (!fast) return launch<EPI, LOAD_GENERIC>(g, stream);
+    const int n_tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    const int slots = 3 * pope_cu_count();  // three resident workgroups per CU (LDS 36.9 KB, <=168 VGPRs)
+    hipLaunchKernelGGL((gemm_nt_f32_persistent_kernel<EPI>), dim3(n_tiles < slots ? n_tiles : slots), dim3(THREADS),
+                       LDS_BYTES, stream, g, n_tiles);
+    return pope_check_launch();
 }
 
 }  // namespace

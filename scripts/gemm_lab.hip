@@ -1,9 +1,8 @@
 // Dev harness (not product): ablations of the fp32 GEMM tile kernel, one process, interleaved.
-#include "../pope_amd/csrc/gemm_core.h"
+#include "../pope_amd/csrc/gemm_f32.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-using namespace gemm_core;
 
 struct P { const float* A; const float* W; float* C; int M, N, K; };
 
@@ -56,6 +55,17 @@ float run(P g, size_t extra) {
     float ms; hipEventElapsedTime(&ms, a, b); return ms;
 }
 
+float run_persistent(P p, int wg_per_cu) {
+    GemmParams g = {};
+    g.A = p.A; g.W = p.W; g.C = p.C; g.M = p.M; g.N = p.N; g.K = p.K; g.lda = p.K; g.ldw = p.K; g.ldc = p.N;
+    const int n_tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a);
+    hipLaunchKernelGGL((gemm_nt_f32_persistent_kernel<EPI_BIAS>), dim3(wg_per_cu * 256), dim3(THREADS), LDS_BYTES, 0, g, n_tiles);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); return ms;
+}
+
 int main() {
     const int M = 64 * 1531;
     size_t na = size_t(M) * 1536, nw = size_t(1536) * 1536, nc = size_t(M) * 1536;
@@ -77,7 +87,8 @@ int main() {
             P g{A, W, C, M, sh.N, sh.K};
             const double gf = 2.0 * M * sh.N * sh.K / 1e9;
             float t0 = run<0, 1>(g, 0), t1 = run<8, 1>(g, 0), t2 = run<0, 0>(g, 0), t3 = run<1, 1>(g, 0),
-                  t4 = run<2, 1>(g, 0), t5 = run<3, 0>(g, 0);
+                  t4 = run<2, 1>(g, 0), t5 = run<3, 0>(g, 0), t6 = run_persistent(g, 3);
+            printf("  %s PERSISTENT %.3f (%.1f TF)\n", sh.name, t6, gf / t6);
             printf("  %s buffer-ld %.3f (%.1f TF) | pointer-ld %.3f (%.1f) | noepi %.3f (%.1f) | noload %.3f (%.1f) | nolds %.3f (%.1f) | mfma+ldsread only %.3f (%.1f)\n",
                    sh.name, t0, gf / t0, t1, gf / t1, t2, gf / t2, t3, gf / t3, t4, gf / t4, t5, gf / t5);
         }
