@@ -13,6 +13,7 @@
 //                      LDS with the matching key order; alpha/normaliser are per-lane scalars.
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -24,10 +25,28 @@ constexpr int ST = 68;    // padded LDS row (floats): 17 x 16 B -> ds_read_b128 
 // independent workgroups whose softmax (VALU) and barrier phases fall under each other's MFMAs.
 constexpr size_t ATTN_LDS_BYTES = size_t(2) * KT * ST * sizeof(float);
 
+// Single-instruction VALU helpers: hipcc would otherwise canonicalise MFMA outputs before fmaxf
+// (one extra v_max per element) and leave most of the packed-f32 forms unused.
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // ABLATE is 0 in the product; the lab harness (scripts/attn_lab.hip) instantiates timing-only
 // variants: bit0 = no softmax VALU, bit1 = no P.V MFMAs, bit2 = no Q.K^T MFMAs.
 template <int ABLATE>
-__global__ __launch_bounds__(256, 3) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                            int N, int heads) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;            // [KT][ST]
@@ -38,9 +57,15 @@ __global__ __launch_bounds__(256, 3) void attn_f32_kernel(const float* __restric
     const int head = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * QB;
     const int D = heads * HD, rs = 3 * D;
     const float* base = qkv + size_t(b) * N * rs;
-    const int koff = D + head * HD, voff = 2 * D + head * HD;
+    const int koff = D + head * HD;
 
-    // Q^T fragments for all 32 k-steps, pre-scaled by head_dim^-0.5 = 0.125 (exact).
+    // Q^T fragments for all 32 k-steps, pre-scaled by head_dim^-0.5 * log2(e): the scores come
+    // out of the MFMA already in the log2 domain, so p = exp2(s - m) is one v_sub + one v_exp_f32.
+    // (On gfx950 the f32 MFMA executes on the SIMD's f32 VALU lanes — measured: every VALU
+    // instruction issued on a SIMD costs its full issue time against the MFMA stream, whichever
+    // wave issues it — so the softmax is written for minimum VALU instruction count: packed
+    // sub/add/mul, max3, no copies.)
+    constexpr float QSCALE = 0.125f * 1.44269504088896340736f;
     f32x4 q[8];
     {
         const int qrow = q0 + wave * 32 + r;
@@ -48,24 +73,25 @@ __global__ __launch_bounds__(256, 3) void attn_f32_kernel(const float* __restric
         for (int j = 0; j < 8; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (qrow < N) v = *reinterpret_cast<const f32x4*>(base + size_t(qrow) * rs + head * HD + 8 * j + 4 * h);
-            q[j] = v * 0.125f;
+            q[j] = v * QSCALE;
         }
     }
 
+    // K/V staging: bounds-checked buffer loads (keys >= N read as zeros): one instruction per
+    // 16-byte piece, no address arithmetic and no branches in the loop.
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, unsigned(N) * unsigned(rs) * 4u, 0x00020000);
     const int srow = tid >> 4, scol = (tid & 15) * 4;
+    unsigned kvoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kvoff[i] = (unsigned(srow + 16 * i) * unsigned(rs) + scol + koff) * 4u;
+    const unsigned tile_bytes = unsigned(KT) * unsigned(rs) * 4u, v_delta = unsigned(D) * 4u;
     f32x4 rk[4], rv[4];
     auto load_kv = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int key = kt * KT + srow + 16 * i;
-            f32x4 zk = {0.f, 0.f, 0.f, 0.f}, zv = {0.f, 0.f, 0.f, 0.f};
-            if (key < N) {
-                const float* p = base + size_t(key) * rs + scol;
-                zk = *reinterpret_cast<const f32x4*>(p + koff);
-                zv = *reinterpret_cast<const f32x4*>(p + voff);
-            }
-            rk[i] = zk;
-            rv[i] = zv;
+            rk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, kvoff[i], kt * tile_bytes, 0));
+            rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, kvoff[i] + v_delta, kt * tile_bytes, 0));
         }
     };
     auto store_kv = [&]() {
@@ -79,15 +105,26 @@ __global__ __launch_bounds__(256, 3) void attn_f32_kernel(const float* __restric
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY;   // running max, log2 domain
+    f32x2 l_run = {0.f, 0.f};  // running sum, two partial lanes (packed adds)
 
-    const int nkt = (N + KT - 1) / KT;
-    load_kv(0);
-    for (int kt = 0; kt < nkt; ++kt) {
+    // V-row base pointers (key rows 8g + 4h of each 32-key half): loop-invariant; laundered through
+    // an empty asm so the compiler keeps them in registers instead of re-deriving them with ~18
+    // v_add_u32 per tile (every VALU instruction is paid against the MFMA stream).
+    typedef __attribute__((address_space(3))) const float* lds_cptr;  // keep the pointers LDS-typed (ds_read, not flat)
+    lds_cptr vbase[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        vbase[g] = (lds_cptr)(&Vs[((g >> 2) * 32 + 8 * (g & 3) + 4 * h) * ST + r]);
+        asm volatile("" : "+v"(vbase[g]));
+    }
+
+    auto tile = [&](int kt, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         if (kt) __syncthreads();  // every wave is done with the previous K/V stage
         store_kv();
         __syncthreads();
-        if (kt + 1 < nkt) load_kv(kt + 1);  // in flight under this tile's 128 MFMAs
+        if constexpr (!LAST) load_kv(kt + 1);  // in flight under this tile's 128 MFMAs
 
         f32x16 s0, s1;
 #pragma unroll
@@ -103,7 +140,7 @@ __global__ __launch_bounds__(256, 3) void attn_f32_kernel(const float* __restric
                 s1 = mfma_32x32x2(k1[s], q[j][s], s1);
             }
         }
-        if (kt == nkt - 1) {  // mask the padded keys of the last tile (wave-uniform branch)
+        if constexpr (LAST) {  // mask the padded keys of the last tile
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = kt * KT + mfma32_row(i, h);
@@ -112,51 +149,65 @@ __global__ __launch_bounds__(256, 3) void attn_f32_kernel(const float* __restric
             }
         }
         if constexpr (!(ABLATE & 1)) {
-        float mt = fmaxf(s0[0], s1[0]);
+            // the MFMA results feed inline-asm VALU ops next: cover the XDL-write -> VALU-read wait
+            // states ourselves (hipcc pads nothing it cannot see inside an asm statement)
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));
+            float mt = vmax3(s0[0], s1[0], s0[1]);
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mt = fmaxf(mt, fmaxf(s0[i], s1[i]));
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
-        float ls = 0.f;
+            for (int i = 1; i < 15; ++i) mt = vmax3(mt, s1[i], s0[i + 1]);
+            mt = vmax3(mt, s1[15], __shfl_xor(vmax3(mt, s1[15], s1[15]), 32));
+            const float m_new = __builtin_fmaxf(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            const f32x2 mm = {m_new, m_new};
+            f32x2 ls = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            s0[i] = __expf(s0[i] - m_new);
-            s1[i] = __expf(s1[i] - m_new);
-            ls += s0[i] + s1[i];
-        }
-        l_run = l_run * alpha + ls;
-        o0 *= alpha;
-        o1 *= alpha;
+            for (int i = 0; i < 16; i += 2) {
+                f32x2 a = pk_sub(f32x2{s0[i], s0[i + 1]}, mm), b = pk_sub(f32x2{s1[i], s1[i + 1]}, mm);
+                a[0] = __builtin_amdgcn_exp2f(a[0]);
+                a[1] = __builtin_amdgcn_exp2f(a[1]);
+                b[0] = __builtin_amdgcn_exp2f(b[0]);
+                b[1] = __builtin_amdgcn_exp2f(b[1]);
+                s0[i] = a[0]; s0[i + 1] = a[1];
+                s1[i] = b[0]; s1[i + 1] = b[1];
+                ls = pk_add(ls, pk_add(a, b));
+            }
+            l_run = l_run * alpha + ls;
+            o0 *= alpha;  // v_pk_mul_f32 x8
+            o1 *= alpha;
         } else {
-            l_run = 1.f;
+            l_run = f32x2{0.5f, 0.5f};
         }
 
-        const float* vb = &Vs[r];
         if constexpr (ABLATE & 2) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[i] += s0[i]; o1[i] += s1[i]; }
         } else {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int row = mfma32_row(t, h);
-            o0 = mfma_32x32x2(vb[row * ST], s0[t], o0);
-            o1 = mfma_32x32x2(vb[row * ST + 32], s0[t], o1);
-        }
+            for (int t = 0; t < 16; ++t) {
+                lds_cptr vb = vbase[t >> 2] + (t & 3) * ST;
+                o0 = mfma_32x32x2(vb[0], s0[t], o0);
+                o1 = mfma_32x32x2(vb[32], s0[t], o1);
+            }
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int row = 32 + mfma32_row(t, h);
-            o0 = mfma_32x32x2(vb[row * ST], s1[t], o0);
-            o1 = mfma_32x32x2(vb[row * ST + 32], s1[t], o1);
+            for (int t = 0; t < 16; ++t) {
+                lds_cptr vb = vbase[4 + (t >> 2)] + (t & 3) * ST;
+                o0 = mfma_32x32x2(vb[0], s1[t], o0);
+                o1 = mfma_32x32x2(vb[32], s1[t], o1);
+            }
         }
-        }
-    }
+    };
+
+    const int nkt = (N + KT - 1) / KT;
+    load_kv(0);
+    for (int kt = 0; kt + 1 < nkt; ++kt) tile(kt, std::false_type{});
+    tile(nkt - 1, std::true_type{});
     __syncthreads();  // the stage is free: reuse it for the O^T transpose
 
     // Normalise, transpose O^T through LDS (K buffers are free after the final barrier; each
     // wave touches only its own 32 rows) and store whole 256-B head rows.
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_half = l_run[0] + l_run[1];
+    const float l_tot = l_half + __shfl_xor(l_half, 32);
     const float inv = 1.0f / l_tot;
     float* Os = smem + (wave * 32) * ST;
 #pragma unroll
