@@ -56,55 +56,22 @@ def gpu_pairs(n_pairs, device, seed):
     return img0, img1
 
 
-def time_kernel(fn, reps=6):
-    """Average duration (ms) of one launch, HIP events on the launch stream (torch's current stream)."""
-    fn()
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in evs:
-        a.record()
-        fn()
-        b.record()
-    torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in evs)
-    return sum(ts) / len(ts)
-
-
-def kernel_table(model, device, chunk):
-    """Per-kernel live timings at the bench shapes (one ViT chunk = `chunk` images)."""
-    from pope_amd import ops
+def kernel_flops(kind, chunk):
+    """Algorithmic FLOPs (2*MAC) of ONE launch of a ViT kernel at the bench shape (chunk images)."""
     rows = chunk * NTOK
-    g = torch.Generator(device=device).manual_seed(1)
-    blk = model.blocks[5]
-    x = torch.randn(rows, DIM, generator=g, device=device)
-    qkv = torch.randn(chunk, NTOK, 3 * DIM, generator=g, device=device)
-    hid = torch.randn(rows, HIDDEN, generator=g, device=device)
-    out_d = torch.zeros(rows, DIM, device=device)
-    out_q = torch.empty(rows, 3 * DIM, device=device)
-    out_h = torch.empty(rows, HIDDEN, device=device)
-    tab = []
+    return {"attention": 4 * chunk * NTOK * NTOK * DIM, "gemm_qkv": 2 * rows * DIM * 3 * DIM,
+            "gemm_proj": 2 * rows * DIM * DIM, "gemm_fc1_gelu": 2 * rows * DIM * HIDDEN,
+            "gemm_fc2": 2 * rows * HIDDEN * DIM,
+            "patch_embed_gemm": 2 * chunk * (NTOK - 1) * 3 * PATCH * PATCH * DIM}.get(kind, 0)
 
-    def add(name, fn, flops, bytes_, launches):
-        ms = time_kernel(fn)
-        tab.append({"kernel": name, "ms": round(ms, 4), "launches_per_step": launches,
-                    "tflops": round(flops / ms / 1e9, 2) if flops else None,
-                    "gbs": round(bytes_ / ms / 1e6, 1), "flops": flops, "bytes": bytes_})
 
-    per_step = lambda n_chunks: n_chunks * DEPTH
-    add("attention_f32", lambda: ops.attention(qkv, HEADS), 4 * chunk * NTOK * NTOK * DIM,
-        rows * 4 * DIM * 4, 1)
-    add("gemm_qkv(bias)", lambda: ops.linear(x, blk.attn.qkv.weight, blk.attn.qkv.bias, out=out_q),
-        2 * rows * DIM * 3 * DIM, rows * 4 * DIM * 4, 1)
-    add("gemm_proj(ls_res)", lambda: ops.linear(x, blk.attn.proj.weight, blk.attn.proj.bias, ops.EPI_BIAS_LS_RES,
-                                                 blk.ls1.gamma, out_d, out=out_d),
-        2 * rows * DIM * DIM, rows * 3 * DIM * 4, 1)
-    add("gemm_fc1(gelu)", lambda: ops.linear(x, blk.mlp.fc1.weight, blk.mlp.fc1.bias, ops.EPI_BIAS_GELU, out=out_h),
-        2 * rows * DIM * HIDDEN, rows * (DIM + HIDDEN) * 4, 1)
-    add("gemm_fc2(ls_res)", lambda: ops.linear(hid, blk.mlp.fc2.weight, blk.mlp.fc2.bias, ops.EPI_BIAS_LS_RES,
-                                                blk.ls2.gamma, out_d, out=out_d),
-        2 * rows * DIM * HIDDEN, rows * (HIDDEN + 2 * DIM) * 4, 1)
-    add("layernorm", lambda: ops.layernorm(x, blk.norm1.weight, blk.norm1.bias), 0, rows * 2 * DIM * 4, 2)
-    return tab
+def kernel_bytes(kind, chunk):
+    """Algorithmic HBM bytes of one launch (activations in + out; weights are L2/MALL resident)."""
+    rows = chunk * NTOK
+    return 4 * {"attention": rows * 4 * DIM, "gemm_qkv": rows * 4 * DIM, "gemm_proj": rows * 3 * DIM,
+                "gemm_fc1_gelu": rows * (DIM + HIDDEN), "gemm_fc2": rows * (HIDDEN + 2 * DIM),
+                "layernorm": rows * 2 * DIM,
+                "patch_embed_gemm": chunk * 3 * H_IMG * W_IMG + rows * DIM}.get(kind, 0)
 
 
 def cpu_baseline(n_pairs):
@@ -163,6 +130,9 @@ def main():
 
     model = load_dinov2_model(state_dict=synth.synthetic_state_dict(seed=0)).to(device)
     pipe = PairPipeline(model, chunk=args.chunk)
+    from pope_amd.profiling import KernelProfiler
+    n_chunks = -(-args.pairs // args.chunk) * 2  # ViT launch sequences per step
+    prof = None if args.no_kernel_table else KernelProfiler(DEPTH, n_chunks * args.steps)
     img0, img1 = gpu_pairs(args.pairs, device, seed=rank)
 
     def step():
@@ -180,11 +150,13 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    model.profiler = prof  # HIP events around every ViT kernel of the TIMED region (launch stream)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, counts = step()
     fence()
     elapsed = time.perf_counter() - t0
+    model.profiler = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -206,19 +178,27 @@ def main():
         "achieved_tflops_whole_step": round(value * flops_per_pair() / 1e12 / world, 2),
         "matches_per_pair_mean": round(float(counts.float().mean()), 1),
     }
-    if rank == 0 and not args.no_kernel_table:
-        tab = kernel_table(model, device, args.chunk)
-        n_chunks = 2 * args.pairs // args.chunk
-        for t in tab:
-            t["ms_per_step"] = round(t["ms"] * t["launches_per_step"] * n_chunks * DEPTH, 3)
-        dom = max((t for t in tab if t["flops"]), key=lambda t: t["ms_per_step"])
+    if prof is not None and rank == 0:
+        tab = []
+        for kind, v in prof.summary().items():
+            fl, by = kernel_flops(kind, args.chunk), kernel_bytes(kind, args.chunk)
+            tab.append({"kernel": kind, "launches": v["launches"], "avg_ms": round(v["avg_ms"], 4),
+                        "ms_per_step": round(v["total_ms"] / args.steps, 3),
+                        "tflops": round(fl / v["avg_ms"] / 1e9, 2) if fl else None,
+                        "gbs": round(by / v["avg_ms"] / 1e6, 1) if by else None, "flops_per_launch": fl})
+        dom = max((t for t in tab if t["flops_per_launch"]), key=lambda t: t["ms_per_step"])
         result["roofline"] = {
             "kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "flops_per_launch": dom["flops"], "ms_per_launch": dom["ms"],
-            "note": "f32-in/f32-acc MFMA (v_mfma_f32_32x32x2_f32) dense peak; HIP events on the launch stream",
+            "flops_per_launch": dom["flops_per_launch"], "avg_ms_per_launch": dom["avg_ms"],
+            "launches_timed": dom["launches"],
+            "note": "algorithmic FLOPs / HIP-event duration of every launch of this kernel inside the timed "
+                    "region (events on the launch stream); peak = dense f32-in/f32-acc MFMA "
+                    "(v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md",
         }
-        result["kernels"] = [{k: t[k] for k in ("kernel", "ms", "ms_per_step", "tflops", "gbs")} for t in tab]
+        result["kernels"] = [{k: t[k] for k in ("kernel", "launches", "avg_ms", "ms_per_step", "tflops", "gbs")}
+                             for t in tab]
+        result["vit_kernel_ms_per_step"] = round(sum(t["ms_per_step"] for t in tab), 3)
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
     if world > 1:

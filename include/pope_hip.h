@@ -90,6 +90,22 @@ int pope_vit_forward_f32(const pope_vit_weights* w_host, const float* img, int B
                          int n_taps, const int* tap_blocks_host, float* const* tap_out_host,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* In-situ kernel timing of the product path (bench.py's roofline leg): identical launches, plus
+ * events_host[i] (hipEvent_t made by pope_event_create) recorded on `stream` immediately before
+ * launch i and one closing event, so consecutive events bracket exactly one kernel.  kinds_host[i]
+ * receives the POPE_K_* id of launch i; *n_launches_host the number of launches (= pope_vit_launch_count). */
+enum { POPE_K_PATCH_EMBED = 0, POPE_K_LAYERNORM = 1, POPE_K_GEMM_QKV = 2, POPE_K_ATTENTION = 3,
+       POPE_K_GEMM_PROJ = 4, POPE_K_GEMM_FC1 = 5, POPE_K_GEMM_FC2 = 6, POPE_K_TAP_COPY = 7 };
+int pope_vit_launch_count(int depth);
+int pope_vit_forward_profiled_f32(const pope_vit_weights* w_host, const float* img, int B, int H, int W,
+                                  const float* posb, float* x_prenorm, float* x_norm,
+                                  void* workspace, size_t workspace_bytes, void* stream,
+                                  void* const* events_host, int n_events, int* kinds_host,
+                                  int* n_launches_host);
+int pope_event_create(void** event_host);
+int pope_event_destroy(void* event);
+int pope_event_elapsed_ms(void* start, void* stop, float* ms_host);  /* both events must have completed */
+
 /* ---- dense matcher --------------------------------------------------------------------------- */
 
 size_t pope_dense_match_workspace_bytes(int n, int L, int S);

@@ -40,6 +40,13 @@ PROTOTYPES = {
     "pope_vit_forward_f32": (C.c_int, [C.POINTER(VitWeights), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int, c_int_p, C.POINTER(C.c_void_p),
                                        C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pope_vit_launch_count": (C.c_int, [C.c_int]),
+    "pope_vit_forward_profiled_f32": (C.c_int, [C.POINTER(VitWeights), C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                C.POINTER(C.c_void_p), C.c_int, c_int_p, c_int_p]),
+    "pope_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "pope_event_destroy": (C.c_int, [C.c_void_p]),
+    "pope_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, c_float_p]),
     "pope_dense_match_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "pope_dense_match_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_float,
                                                                                   C.c_float] + [C.c_void_p] * 8

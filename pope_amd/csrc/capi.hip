@@ -8,6 +8,23 @@ namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Optional in-situ timing: events[i] is recorded on the stream right before launch i and one more
+// after the last launch, so events[i]..events[i+1] bracket exactly one kernel of the product path.
+struct Recorder {
+    void* const* events;
+    int capacity;
+    int* kinds;
+    int n;
+    bool mark(int kind, hipStream_t stream) {
+        if (!events) return true;
+        if (n >= capacity) return false;
+        if (hipEventRecord(static_cast<hipEvent_t>(events[n]), stream) != hipSuccess) return false;
+        if (kinds && kind >= 0) kinds[n] = kind;
+        ++n;
+        return true;
+    }
+};
+
 __global__ __launch_bounds__(256) void cls_cosine_kernel(const float* __restrict__ ref, const float* __restrict__ fea,
                                                           int P, int D, float eps, float* __restrict__ scores) {
     // x.y / (max(|x|, eps) * max(|y|, eps)) — torch semantics, each norm clamped separately
@@ -96,9 +113,10 @@ size_t pope_vit_workspace_bytes(int B, int ntok, int dim, int hidden) {
     return align_up(rows * dim * sizeof(float), 256) + align_up(rows * big * sizeof(float), 256);
 }
 
-int pope_vit_forward_f32(const pope_vit_weights* w, const float* img, int B, int H, int W, const float* posb,
-                         float* x_prenorm, float* x_norm, int n_taps, const int* tap_blocks_host,
-                         float* const* tap_out_host, void* workspace, size_t workspace_bytes, void* stream_) {
+static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, int H, int W, const float* posb,
+                            float* x_prenorm, float* x_norm, int n_taps, const int* tap_blocks_host,
+                            float* const* tap_out_host, void* workspace, size_t workspace_bytes, void* stream_,
+                            Recorder& rec) {
     if (!w || !img || !posb || !x_prenorm || !workspace || !w->blocks_host) return POPE_ERR_ARG;
     if (w->dim != w->heads * 64 || w->patch <= 0 || H % w->patch || W % w->patch || B <= 0) return POPE_ERR_ARG;
     if (n_taps < 0 || (n_taps > 0 && (!tap_blocks_host || !tap_out_host))) return POPE_ERR_ARG;
@@ -118,28 +136,82 @@ int pope_vit_forward_f32(const pope_vit_weights* w, const float* img, int B, int
     float* x = x_prenorm;
     const float eps = 1e-6f;  // vision_transformer.py:90
 
+#define POPE_MARK(kind) do { if (!rec.mark(kind, stream)) return POPE_ERR_ARG; } while (0)
+    POPE_MARK(POPE_K_PATCH_EMBED);
     int rc = pope_patch_embed_f32(img, w->patch_w, posb, x, B, H, W, w->patch, dim, stream);
     if (rc) return rc;
     for (int i = 0; i < w->depth; ++i) {
         const pope_vit_block_weights& k = w->blocks_host[i];
         // x = x + ls1(attn(norm1(x)))                                      block.py:105
+        POPE_MARK(POPE_K_LAYERNORM);
         if ((rc = pope_launch_layernorm_f32(x, dim, k.norm1_w, k.norm1_b, xn, dim, rows, dim, eps, stream))) return rc;
+        POPE_MARK(POPE_K_GEMM_QKV);
         if ((rc = pope_linear_f32(xn, k.qkv_w, k.qkv_b, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, stream))) return rc;
+        POPE_MARK(POPE_K_ATTENTION);
         if ((rc = pope_launch_attention_f32(qkv, att, B, ntok, w->heads, stream))) return rc;
+        POPE_MARK(POPE_K_GEMM_PROJ);
         if ((rc = pope_linear_f32(att, k.proj_w, k.proj_b, x, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, stream))) return rc;
         // x = x + ls2(mlp(norm2(x)))                                       block.py:106
+        POPE_MARK(POPE_K_LAYERNORM);
         if ((rc = pope_launch_layernorm_f32(x, dim, k.norm2_w, k.norm2_b, xn, dim, rows, dim, eps, stream))) return rc;
+        POPE_MARK(POPE_K_GEMM_FC1);
         if ((rc = pope_linear_f32(xn, k.fc1_w, k.fc1_b, hid, rows, hidden, dim, EPI_BIAS_GELU, nullptr, nullptr, stream))) return rc;
+        POPE_MARK(POPE_K_GEMM_FC2);
         if ((rc = pope_linear_f32(hid, k.fc2_w, k.fc2_b, x, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x, stream))) return rc;
         for (int t = 0; t < n_taps; ++t)
-            if (tap_blocks_host[t] == i && tap_out_host[t])
+            if (tap_blocks_host[t] == i && tap_out_host[t]) {
+                POPE_MARK(POPE_K_TAP_COPY);
                 if (hipMemcpyAsync(tap_out_host[t], x, size_t(rows) * dim * sizeof(float), hipMemcpyDeviceToDevice,
                                    stream) != hipSuccess)
                     return POPE_ERR_LAUNCH;
+            }
     }
-    if (x_norm)
+    if (x_norm) {
+        POPE_MARK(POPE_K_LAYERNORM);
         if ((rc = pope_launch_layernorm_f32(x, dim, w->norm_w, w->norm_b, x_norm, dim, rows, dim, eps, stream))) return rc;
+    }
+    POPE_MARK(-1);  // closing event
+#undef POPE_MARK
     return POPE_OK;
+}
+
+
+int pope_vit_forward_f32(const pope_vit_weights* w, const float* img, int B, int H, int W, const float* posb,
+                         float* x_prenorm, float* x_norm, int n_taps, const int* tap_blocks_host,
+                         float* const* tap_out_host, void* workspace, size_t workspace_bytes, void* stream) {
+    Recorder rec = {nullptr, 0, nullptr, 0};
+    return vit_forward_impl(w, img, B, H, W, posb, x_prenorm, x_norm, n_taps, tap_blocks_host, tap_out_host, workspace,
+                            workspace_bytes, stream, rec);
+}
+
+int pope_vit_forward_profiled_f32(const pope_vit_weights* w, const float* img, int B, int H, int W, const float* posb,
+                                  float* x_prenorm, float* x_norm, void* workspace, size_t workspace_bytes,
+                                  void* stream, void* const* events_host, int n_events, int* kinds_host,
+                                  int* n_launches_host) {
+    if (!events_host || n_events < 2 || !kinds_host || !n_launches_host) return POPE_ERR_ARG;
+    Recorder rec = {events_host, n_events, kinds_host, 0};
+    const int rc = vit_forward_impl(w, img, B, H, W, posb, x_prenorm, x_norm, 0, nullptr, nullptr, workspace,
+                                    workspace_bytes, stream, rec);
+    *n_launches_host = rec.n > 0 ? rec.n - 1 : 0;
+    return rc;
+}
+
+int pope_vit_launch_count(int depth) { return depth > 0 ? 7 * depth + 2 : 0; }
+
+int pope_event_create(void** event_host) {
+    if (!event_host) return POPE_ERR_ARG;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return POPE_ERR_LAUNCH;
+    *event_host = e;
+    return POPE_OK;
+}
+int pope_event_destroy(void* event) {
+    return hipEventDestroy(static_cast<hipEvent_t>(event)) == hipSuccess ? POPE_OK : POPE_ERR_LAUNCH;
+}
+int pope_event_elapsed_ms(void* start, void* stop, float* ms_host) {
+    if (!ms_host) return POPE_ERR_ARG;
+    return hipEventElapsedTime(ms_host, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)) == hipSuccess
+               ? POPE_OK : POPE_ERR_LAUNCH;
 }
 
 size_t pope_dense_match_workspace_bytes(int n, int L, int S) {

@@ -1,6 +1,7 @@
 // Shared 128x128x32 fp32-MFMA tile mainloop + coalesced epilogue (see gemm_f32.hip for the design).
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace gemm_core {
 
@@ -69,18 +70,15 @@ __device__ __forceinline__ void mainloop_prefetched(const LoaderA& la, const Loa
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
     const int srow = tid >> 3, scol = (tid & 7) * 4;
 
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
-
     const int nk = (K + BK - 1) / BK;
     const float* a_base = &As[(wm * 64 + r) * LDS_ST + 4 * h];
     const float* w_base = &Ws[(wn * 64 + r) * LDS_ST + 4 * h];
-    for (int kt = 0; kt < nk; ++kt) {
-        if (!(LAB & 2) || kt == 0) {
+    // One K-step.  The first step of a tile starts its accumulation chains from the MFMA's inline
+    // zero C operand instead of zero-filled registers (64 v_mov per tile saved: VALU instructions
+    // are paid against the f32 MFMA stream, which runs on the same lanes).
+    auto kstep = [&](int kt, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        if (!(LAB & 2) || FIRST) {
             __syncthreads();  // every wave is done reading the previous stage / epilogue staging
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -117,10 +115,18 @@ __device__ __forceinline__ void mainloop_prefetched(const LoaderA& la, const Loa
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = mfma_32x32x2(b[ni][s], a[mi][s], acc[mi][ni]);
+                    for (int ni = 0; ni < 2; ++ni) {
+                        if (FIRST && j == 0 && s == 0) {
+                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[mi][ni] = mfma_32x32x2(b[ni][s], a[mi][s], zero);
+                        } else {
+                            acc[mi][ni] = mfma_32x32x2(b[ni][s], a[mi][s], acc[mi][ni]);
+                        }
+                    }
         }
-    }
+    };
+    kstep(0, std::true_type{});
+    for (int kt = 1; kt < nk; ++kt) kstep(kt, std::false_type{});
 }
 
 // One tile, no cross-tile prefetch.

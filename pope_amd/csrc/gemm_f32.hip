@@ -19,9 +19,33 @@ namespace {
 
 using namespace gemm_core;
 
-__device__ __forceinline__ float gelu_erf(float x) {
-    // nn.GELU() default = exact erf form
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+// nn.GELU() default = exact erf form, 0.5 x (1 + erf(x / sqrt 2)), evaluated
+// branch-free on element PAIRS with packed f32 math: the f32 MFMA shares the SIMD's VALU lanes, so
+// the epilogue's instruction count is paid in full against the matrix stream (ocml erff: ~35 VALU
+// per element with divergent range branches = ~20 % of an FC1 tile).  erfc via Abramowitz-Stegun
+// 7.1.26 (|err| <= 1.5e-7): with z = |x|/sqrt2, t = 1/(1 + p z), q = 0.5 t P(t) exp(-z^2):
+//   gelu(x) = x (1 - q) for x >= 0,  x q for x < 0   ==   relu(x) (1 - 2q) + x q.
+// Max abs error vs the exact form over [-12, 12] in fp32: 4.7e-7 (one ulp at |x| ~ 4).
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    constexpr float P = 0.3275911f * 0.70710678118654752440f;
+    constexpr float A1 = 0.5f * 0.254829592f, A2 = 0.5f * -0.284496736f, A3 = 0.5f * 1.421413741f,
+                    A4 = 0.5f * -1.453152027f, A5 = 0.5f * 1.061405429f;
+    constexpr float NHL2E = -0.5f * 1.44269504088896340736f;  // exp(-x^2/2) = exp2(x * x * NHL2E)
+    f32x2 t, e, relu;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        t[i] = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x[i]), P, 1.0f));
+        relu[i] = __builtin_fmaxf(x[i], 0.0f);
+    }
+    const f32x2 arg = (x * NHL2E) * x;
+    e[0] = __builtin_amdgcn_exp2f(arg[0]);
+    e[1] = __builtin_amdgcn_exp2f(arg[1]);
+    f32x2 poly = __builtin_elementwise_fma(t, f32x2{A5, A5}, f32x2{A4, A4});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{A3, A3});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{A2, A2});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{A1, A1});
+    const f32x2 q = (poly * t) * e;
+    return __builtin_elementwise_fma(relu, __builtin_elementwise_fma(q, f32x2{-2.f, -2.f}, f32x2{1.f, 1.f}), x * q);
 }
 
 template <bool PATCH>
@@ -70,8 +94,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& g, int m0, int n
             v = v + bias;
         } else if constexpr (EPI == EPI_BIAS_GELU) {
             v = v + bias;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            const f32x2 lo = gelu_erf2(f32x2{v[0], v[1]}), hi = gelu_erf2(f32x2{v[2], v[3]});
+            v = f32x4{lo[0], lo[1], hi[0], hi[1]};
         } else if constexpr (EPI == EPI_BIAS_LS_RES) {
             const f32x4 gamma = *reinterpret_cast<const f32x4*>(g.gamma + col);
             const f32x4 res = *reinterpret_cast<const f32x4*>(g.res + size_t(row) * g.ldres + col);
@@ -85,16 +109,20 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& g, int m0, int n
 
 enum { LOAD_GENERIC = 0, LOAD_BUFFER = 1, LOAD_PATCH = 2 };
 
-// One tile per workgroup (generic pointer loader / im2col gather loader).
+// One tile per workgroup (hardware dispatcher refills the three slots per CU as tiles retire).
 template <int EPI, int LOADER>
-__global__ __launch_bounds__(THREADS, 3) void gemm_nt_f32_kernel(const GemmParams g) {
+__global__ __launch_bounds__(THREADS, LOADER == LOAD_PATCH ? 2 : 3) void gemm_nt_f32_kernel(const GemmParams g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tiles_n = (g.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     f32x16 acc[2][2];
-    mainloop(fn_loader([&](int row, int k) { return load_a<LOADER == LOAD_PATCH>(g, m0 + row, k); }),
-             fn_loader([&](int row, int k) { return load_w(g, n0 + row, k); }), g.K, smem, acc);
+    if constexpr (LOADER == LOAD_BUFFER) {
+        mainloop(BufferLoader(g.A, g.M, g.lda, m0), BufferLoader(g.W, g.N, g.ldw, n0), g.K, smem, acc);
+    } else {
+        mainloop(fn_loader([&](int row, int k) { return load_a<LOADER == LOAD_PATCH>(g, m0 + row, k); }),
+                 fn_loader([&](int row, int k) { return load_w(g, n0 + row, k); }), g.K, smem, acc);
+    }
     tile_epilogue<EPI>(g, m0, n0, acc, smem);
 }
 
@@ -145,6 +173,10 @@ int launch_linear(const GemmParams& g, hipStream_t stream) {
     if (!fast) return launch<EPI, LOAD_GENERIC>(g, stream);
     const int n_tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     const int slots = 3 * pope_cu_count();  // three resident workgroups per CU (LDS 36.9 KB, <=168 VGPRs)
+    // Persistent streaming pays only when a slot sees few, short tiles (proj: 3 tiles of K=384 per
+    // slot: +4 %); with more or longer tiles per slot the dispatcher's refill is 2-5 % faster
+    // (lab A/B at M = 97 984: qkv 133 vs 131, fc1 137 vs 131, fc2 142 vs 139 TF/s).
+    if (size_t(n_tiles) * g.K >= size_t(2048) * slots) return launch<EPI, LOAD_BUFFER>(g, stream);
     hipLaunchKernelGGL((gemm_nt_f32_persistent_kernel<EPI>), dim3(n_tiles < slots ? n_tiles : slots), dim3(THREADS),
                        LDS_BYTES, stream, g, n_tiles);
     return pope_check_launch();

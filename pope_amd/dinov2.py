@@ -105,6 +105,7 @@ class DinoVisionTransformer(nn.Module):
         self._wcache = None
         self._posb_cache = {}
         self._ws = None
+        self.profiler = None  # optional pope_amd.profiling.KernelProfiler (in-situ kernel timing)
         for p in self.parameters():
             p.requires_grad_(False)  # inference-only kernels
 
@@ -215,6 +216,15 @@ class DinoVisionTransformer(nn.Module):
         tap_out = [torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32) for _ in taps]
         tap_blocks = (C.c_int * max(1, len(taps)))(*taps)
         tap_ptrs = (C.c_void_p * max(1, len(taps)))(*[t.data_ptr() for t in tap_out])
+        slot = self.profiler.next_slot() if (self.profiler is not None and not taps) else None
+        if slot is not None:
+            off, ev, cap, kinds = slot
+            n_launch = C.c_int()
+            check(L.pope_vit_forward_profiled_f32(C.byref(w), ptr(x), B, H, W, ptr(posb), ptr(x_pre), ptr(x_norm),
+                                                  C.c_void_p(ws.data_ptr()), ws.numel(), stream_of(x.device), ev, cap,
+                                                  kinds, C.byref(n_launch)), "pope_vit_forward_profiled_f32")
+            self.profiler.commit(off, n_launch.value)
+            return x_pre, x_norm, tap_out
         check(L.pope_vit_forward_f32(C.byref(w), ptr(x), B, H, W, ptr(posb), ptr(x_pre), ptr(x_norm),
                                      len(taps), tap_blocks, tap_ptrs, C.c_void_p(ws.data_ptr()), ws.numel(),
                                      stream_of(x.device)), "pope_vit_forward_f32")
