@@ -1,0 +1,32 @@
+"""Hot-path subset of the reference façade `pope_model_api.py` (star-imported by the drivers,
+eval_linemod_json.py:1).  Exports, under the reference's names, everything of that namespace that
+lies on the accelerated path; names that belong to out-of-scope stages (SAM proposal
+generator, OpenCV pose solver, LoFTR CNN stages) are not re-implemented here — the reference's own
+modules keep providing them.
+
+Unlike the reference façade, importing this module has no side effects (the reference builds the
+LoFTR `matcher` singleton from weights/matcher.pth at import, pope_model_api.py:177-185).
+"""
+import json  # noqa: F401  (re-exported like the reference does)
+import os  # noqa: F401
+import time  # noqa: F401
+
+import numpy as np  # noqa: F401
+import torch  # noqa: F401
+import torch.nn.functional as F  # noqa: F401
+
+from .dinov2_utils import get_cls_token_torch, load_dinov2_model, set_torch_image  # noqa: F401
+from .matcher import CoarseMatching, default_cfg, dense_match  # noqa: F401
+from .ops import cls_cosine, streaming_top3  # noqa: F401
+from .pipeline import PairPipeline, gather_counts, shard_range  # noqa: F401
+
+
+def vote_top3(model, ref_tensor, crop_tensors):
+    """Hot loop #1 of the drivers (eval_linemod_json.py:65,74-101) batched: CLS token of the reference
+    crop vs P proposal crops -> cosine scores -> streaming top-3 slots (same slot order as the
+    reference's sequential loop).  Returns (scores[P] (cuda), slot_scores[3], slot_index[3])."""
+    ref = get_cls_token_torch(model, ref_tensor)
+    fea = get_cls_token_torch(model, crop_tensors)
+    scores = cls_cosine(ref, fea, eps=1e-8)
+    slots, idx = streaming_top3(scores.cpu().numpy())
+    return scores, slots, idx

@@ -80,3 +80,24 @@ def test_full_size_properties(model):
     assert float(z.mean(-1).abs().max()) < 1e-4 and float((z.var(-1, unbiased=False) - 1).abs().max()) < 1e-3
     single = model(x[4:5], is_training=True)["x_norm_patchtokens"]
     assert torch.equal(single, out["x_norm_patchtokens"][4:5])
+
+
+def test_vote_top3_matches_reference_loop(model, sd0):
+    """Batched CLS scoring + streaming top-3 == the reference's sequential per-proposal loop run on the
+    CPU oracle (eval_linemod_json.py:65,74-101): identical slot assignment."""
+    import torch.nn.functional as F
+    from oracle import coarse_match_ref as cm
+    from oracle import dinov2_ref
+    from pope_amd import synth
+    from pope_amd.pope_model_api import vote_top3
+    ref_img = synth.synthetic_images(1, 196, 196, seed=40)
+    crops = synth.synthetic_images(9, 196, 196, seed=41)
+    crops[4] = ref_img[0] * 0.9 + 0.1 * crops[4]   # a near-duplicate proposal must win a slot
+    crops[7] = crops[2]                             # exact tie between two proposals
+    scores, slots, idx = vote_top3(model, ref_img.cuda(), crops.cuda())
+    ref_cls = dinov2_ref.forward(sd0, ref_img)
+    want_scores = torch.cat([F.cosine_similarity(ref_cls, dinov2_ref.forward(sd0, crops[i:i + 1]), dim=1, eps=1e-8)
+                             for i in range(9)])
+    np.testing.assert_allclose(scores.cpu().numpy(), want_scores.numpy(), rtol=0, atol=1e-5)
+    _, want_idx = cm.streaming_top3(want_scores.numpy())
+    assert list(idx) == list(want_idx) and 4 in idx
