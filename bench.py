@@ -187,9 +187,16 @@ def main():
                         "tflops": round(fl / v["avg_ms"] / 1e9, 2) if fl else None,
                         "gbs": round(by / v["avg_ms"] / 1e6, 1) if by else None, "flops_per_launch": fl})
         dom = max((t for t in tab if t["flops_per_launch"]), key=lambda t: t["ms_per_step"])
+        traffic = None  # PMC-derived bytes per launch, collected in separate rocprofv3 --pmc passes (profiles/)
+        try:
+            key = dom["kernel"]
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
+        except (OSError, ValueError):
+            pass
         result["roofline"] = {
             "kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": kernel_bytes(dom["kernel"], args.chunk),
             "flops_per_launch": dom["flops_per_launch"], "avg_ms_per_launch": dom["avg_ms"],
             "launches_timed": dom["launches"],
             "note": "algorithmic FLOPs / HIP-event duration of every launch of this kernel inside the timed "

@@ -54,7 +54,12 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * QB;
+    // 1-D grid, XCD-aware: the query blocks of one (image, head) get consecutive logical ids, i.e.
+    // run on ONE XCD, so its private L2 serves their K/V re-reads (12 query blocks re-read the
+    // same 784 KB; spread round-robin over the 8 XCDs the fabric saw 4.6x the algorithmic bytes).
+    const int n_qb = (N + QB - 1) / QB;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = logical / n_qb, head = bh % heads, b = bh / heads, q0 = (logical - bh * n_qb) * QB;
     const int D = heads * HD, rs = 3 * D;
     const float* base = qkv + size_t(b) * N * rs;
     const int koff = D + head * HD;
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
 }  // namespace
 
 int pope_launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream) {
-    if (B <= 0 || N <= 0 || heads <= 0 || B > 65535 || heads > 65535) return POPE_ERR_ARG;
+    if (B <= 0 || N <= 0 || heads <= 0 || size_t(B) * heads * ((N + QB - 1) / QB) > 0x7fffffffull) return POPE_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return POPE_ERR_ARG;
     static bool attr_set = false;
     if (!attr_set) {
@@ -240,7 +245,7 @@ int pope_launch_attention_f32(const float* qkv, float* out, int B, int N, int he
             return POPE_ERR_LAUNCH;
         attr_set = true;
     }
-    const dim3 grid((N + QB - 1) / QB, heads, B);
+    const dim3 grid(unsigned((N + QB - 1) / QB) * heads * B);
     hipLaunchKernelGGL(attn_f32_kernel<0>, grid, dim3(256), ATTN_LDS_BYTES, stream, qkv, out, N, heads);
     return pope_check_launch();
 }

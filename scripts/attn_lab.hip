@@ -9,7 +9,7 @@ template <int AB>
 float run(const float* qkv, float* out, int B, int N, int heads, size_t extra_lds) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_kernel<AB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         int(ATTN_LDS_BYTES + extra_lds));
-    dim3 grid((N + QB - 1) / QB, heads, B);
+    dim3 grid(unsigned((N + QB - 1) / QB) * heads * B);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     hipEventRecord(a);
