@@ -24,15 +24,19 @@ class VitBlockWeights(C.Structure):
 class VitWeights(C.Structure):
     _fields_ = [("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int), ("patch", C.c_int),
                 ("hidden", C.c_int), ("patch_w", C.c_void_p), ("norm_w", C.c_void_p),
-                ("norm_b", C.c_void_p), ("blocks_host", C.POINTER(VitBlockWeights))]
+                ("norm_b", C.c_void_p), ("blocks_host", C.POINTER(VitBlockWeights)), ("precision", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/pope_hip.h
+PREC_F32_MFMA, PREC_F16X3 = 0, 1
+PRECISIONS = {"f32": PREC_F32_MFMA, "f16x3": PREC_F16X3}
+
 PROTOTYPES = {
     "pope_abi_version": (C.c_int, []),
     "pope_error_string": (C.c_char_p, [C.c_int]),
     "pope_layernorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pope_linear_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 3),
+    "pope_linear_prec_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 2 + [C.c_int, C.c_void_p]),
     "pope_patch_embed_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "pope_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pope_cls_cosine_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

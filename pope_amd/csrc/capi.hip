@@ -69,13 +69,22 @@ int pope_layernorm_f32(const float* x, const float* weight, const float* bias, f
 
 int pope_linear_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
                     int epilogue, const float* gamma, const float* res, void* stream) {
+    return pope_linear_prec_f32(A, W, bias, C, M, N, K, epilogue, gamma, res, POPE_PREC_F32_MFMA, stream);
+}
+
+int pope_linear_prec_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
+                         int epilogue, const float* gamma, const float* res, int precision, void* stream) {
     if (!A || !W || !C || epilogue < 0 || epilogue > POPE_EPI_BIAS_LS_RES) return POPE_ERR_ARG;
+    if (precision != POPE_PREC_F32_MFMA && precision != POPE_PREC_F16X3) return POPE_ERR_ARG;
     GemmParams g = {};
     g.A = A; g.W = W; g.bias = bias; g.C = C;
     g.lda = K; g.ldw = K; g.ldc = N;
     g.M = M; g.N = N; g.K = K;
     g.epilogue = epilogue;
     g.gamma = gamma; g.res = res; g.ldres = N;
+    // shapes the f16x3 kernel does not take (K % 32 != 0) run on the fp32 MFMA: same contract, same results
+    if (precision == POPE_PREC_F16X3 && pope_gemm_f16x3_supported(g))
+        return pope_launch_gemm_nt_f16x3(g, static_cast<hipStream_t>(stream));
     return pope_launch_gemm_nt_f32(g, static_cast<hipStream_t>(stream));
 }
 
@@ -121,7 +130,8 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
     if (w->dim != w->heads * 64 || w->patch <= 0 || H % w->patch || W % w->patch || B <= 0) return POPE_ERR_ARG;
     if (n_taps < 0 || (n_taps > 0 && (!tap_blocks_host || !tap_out_host))) return POPE_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int dim = w->dim, hidden = w->hidden;
+    const int dim = w->dim, hidden = w->hidden, prec = w->precision;
+    if (prec != POPE_PREC_F32_MFMA && prec != POPE_PREC_F16X3) return POPE_ERR_ARG;
     const int ntok = 1 + (H / w->patch) * (W / w->patch);
     const int rows = B * ntok;
     if (workspace_bytes < pope_vit_workspace_bytes(B, ntok, dim, hidden)) return POPE_ERR_WORKSPACE;
@@ -146,18 +156,18 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
         POPE_MARK(POPE_K_LAYERNORM);
         if ((rc = pope_launch_layernorm_f32(x, dim, k.norm1_w, k.norm1_b, xn, dim, rows, dim, eps, stream))) return rc;
         POPE_MARK(POPE_K_GEMM_QKV);
-        if ((rc = pope_linear_f32(xn, k.qkv_w, k.qkv_b, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, stream))) return rc;
+        if ((rc = pope_linear_prec_f32(xn, k.qkv_w, k.qkv_b, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, prec, stream))) return rc;
         POPE_MARK(POPE_K_ATTENTION);
         if ((rc = pope_launch_attention_f32(qkv, att, B, ntok, w->heads, stream))) return rc;
         POPE_MARK(POPE_K_GEMM_PROJ);
-        if ((rc = pope_linear_f32(att, k.proj_w, k.proj_b, x, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, stream))) return rc;
+        if ((rc = pope_linear_prec_f32(att, k.proj_w, k.proj_b, x, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, prec, stream))) return rc;
         // x = x + ls2(mlp(norm2(x)))                                       block.py:106
         POPE_MARK(POPE_K_LAYERNORM);
         if ((rc = pope_launch_layernorm_f32(x, dim, k.norm2_w, k.norm2_b, xn, dim, rows, dim, eps, stream))) return rc;
         POPE_MARK(POPE_K_GEMM_FC1);
-        if ((rc = pope_linear_f32(xn, k.fc1_w, k.fc1_b, hid, rows, hidden, dim, EPI_BIAS_GELU, nullptr, nullptr, stream))) return rc;
+        if ((rc = pope_linear_prec_f32(xn, k.fc1_w, k.fc1_b, hid, rows, hidden, dim, EPI_BIAS_GELU, nullptr, nullptr, prec, stream))) return rc;
         POPE_MARK(POPE_K_GEMM_FC2);
-        if ((rc = pope_linear_f32(hid, k.fc2_w, k.fc2_b, x, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x, stream))) return rc;
+        if ((rc = pope_linear_prec_f32(hid, k.fc2_w, k.fc2_b, x, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x, prec, stream))) return rc;
         for (int t = 0; t < n_taps; ++t)
             if (tap_blocks_host[t] == i && tap_out_host[t]) {
                 POPE_MARK(POPE_K_TAP_COPY);

@@ -28,6 +28,10 @@ struct GemmParams {
 
 int pope_launch_gemm_nt_f32(const GemmParams& g, hipStream_t stream);
 
+// Same contract on the f16 matrix cores with error-compensated operands (gemm_f16x3.hip).
+bool pope_gemm_f16x3_supported(const GemmParams& g);
+int pope_launch_gemm_nt_f16x3(const GemmParams& g, hipStream_t stream);
+
 // y[r,:] = LayerNorm(x[r,:]) * w + b over `dim` (multiple of 128, <= 2048), eps inside the sqrt.
 int pope_launch_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
                               int rows, int dim, float eps, hipStream_t stream);

@@ -24,6 +24,9 @@ from . import _lib
 from ._lib import check, ptr, require_cuda, stream_of
 
 
+DEFAULT_PRECISION = "f16x3"
+
+
 class _PatchEmbed(nn.Module):
     def __init__(self, img_size, patch_size, in_chans, embed_dim):
         super().__init__()
@@ -106,6 +109,7 @@ class DinoVisionTransformer(nn.Module):
         self._posb_cache = {}
         self._ws = None
         self.profiler = None  # optional pope_amd.profiling.KernelProfiler (in-situ kernel timing)
+        self.precision = DEFAULT_PRECISION  # arithmetic of the Linear layers: "f16x3" or "f32" (_lib.PRECISIONS)
         for p in self.parameters():
             p.requires_grad_(False)  # inference-only kernels
 
@@ -131,7 +135,7 @@ class DinoVisionTransformer(nn.Module):
 
     def _weights(self):
         dev_ptr = self.cls_token.data_ptr()
-        if self._wcache is not None and self._wcache[0] == dev_ptr:
+        if self._wcache is not None and self._wcache[0] == dev_ptr and self._wcache[4] == self.precision:
             return self._wcache[1]
         tensors = []
 
@@ -152,8 +156,8 @@ class DinoVisionTransformer(nn.Module):
         w = _lib.VitWeights(self.embed_dim, self.n_blocks, self.num_heads, self.patch_size,
                             self.blocks[0].mlp.fc1.weight.shape[0],
                             P(self.patch_embed.proj.weight.reshape(self.embed_dim, -1)),
-                            P(self.norm.weight), P(self.norm.bias), blocks)
-        self._wcache = (dev_ptr, w, blocks, tensors)
+                            P(self.norm.weight), P(self.norm.bias), blocks, _lib.PRECISIONS[self.precision])
+        self._wcache = (dev_ptr, w, blocks, tensors, self.precision)
         return w
 
     # ---- positional encoding (host plumbing, cached per (H, W)) -----------------------------

@@ -26,8 +26,9 @@ def layernorm(x, weight, bias, eps=1e-6):
     return y
 
 
-def linear(a, weight, bias=None, epilogue=EPI_BIAS, gamma=None, res=None, out=None):
-    """nn.Linear with fused epilogue: bias | bias+GELU(erf) | res + gamma*(.+bias)."""
+def linear(a, weight, bias=None, epilogue=EPI_BIAS, gamma=None, res=None, out=None, precision="f32"):
+    """nn.Linear with fused epilogue: bias | bias+GELU(erf) | res + gamma*(.+bias).
+    precision: "f32" (exact fp32 MFMA chain) or "f16x3" (error-compensated f16 matrix cores)."""
     a = _f32c(a, "linear")
     weight = _f32c(weight, "linear.w")
     n, k = weight.shape
@@ -35,8 +36,8 @@ def linear(a, weight, bias=None, epilogue=EPI_BIAS, gamma=None, res=None, out=No
     m = a.numel() // k
     if out is None:
         out = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32)
-    check(_lib.lib().pope_linear_f32(ptr(a), ptr(weight), ptr(bias), ptr(out), m, n, k, epilogue, ptr(gamma),
-                                     ptr(res), stream_of(a.device)), "pope_linear_f32")
+    check(_lib.lib().pope_linear_prec_f32(ptr(a), ptr(weight), ptr(bias), ptr(out), m, n, k, epilogue, ptr(gamma),
+                                          ptr(res), _lib.PRECISIONS[precision], stream_of(a.device)), "pope_linear_prec_f32")
     return out
 
 

@@ -33,42 +33,65 @@ def test_layernorm(dev, rows, dim):
     _close(got, want, atol=2e-6)
 
 
+PRECS = ["f32", "f16x3"]
+
+
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("M,N,K", [(1, 384, 384), (130, 1152, 384), (394, 1536, 384), (257, 384, 1536),
                                     (1531, 1152, 384), (129, 100, 36)])
-def test_linear_bias(dev, M, N, K):
+def test_linear_bias(dev, M, N, K, prec):
     from pope_amd import ops
     a, w, b = _rand(M, K, seed=4), _rand(N, K, seed=5, scale=K ** -0.5), _rand(N, seed=6)
-    want = F.linear(a, w, b)
-    got = ops.linear(a.to(dev), w.to(dev), b.to(dev))
+    want = F.linear(a.double(), w.double(), b.double()).float()
+    got = ops.linear(a.to(dev), w.to(dev), b.to(dev), precision=prec)
     _close(got, want, atol=1e-5, rtol=1e-5)
 
 
-def test_linear_is_exact_fma_chain_on_integers(dev):
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 300.0, 1e4])  # |a| stays below the f16 range limit 65504
+def test_linear_f16x3_dynamic_range(dev, scale):
+    # the split representation is relative (2^-22) above 2^-3 and absolute (2^-25) below; products of
+    # activations at `scale` with O(0.05) weights must stay at fp32-chain accuracy up to the f16 range
+    from pope_amd import ops
+    a, w = _rand(300, 384, seed=21, scale=scale), _rand(384, 384, seed=22, scale=0.05)
+    want = (a.double() @ w.double().t()).float()
+    got32 = ops.linear(a.to(dev), w.to(dev), precision="f32").cpu()
+    got16 = ops.linear(a.to(dev), w.to(dev), precision="f16x3").cpu()
+    e32, e16 = float((got32 - want).abs().max()), float((got16 - want).abs().max())
+    ref = float(want.abs().max())
+    print(f"scale {scale:g}: max|err| f32-chain {e32:.2e}  f16x3 {e16:.2e}  (|out| max {ref:.2e})")
+    assert e16 <= max(4 * e32, 2e-6 * ref)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_linear_is_exact_fma_chain_on_integers(dev, prec):
     # integer-valued operands: every product and partial sum is exact in fp32, so any operand-map
     # or k-permutation error shows up as a wrong integer (asymmetric W: catches transposes)
     from pope_amd import ops
     g = torch.Generator().manual_seed(7)
     a = torch.randint(-4, 5, (200, 96), generator=g).float()
     w = torch.randint(-4, 5, (136, 96), generator=g).float()
-    got = ops.linear(a.to(dev), w.to(dev))
+    got = ops.linear(a.to(dev), w.to(dev), precision=prec)
     assert torch.equal(got.cpu(), a @ w.t())
 
 
-def test_linear_gelu(dev):
+@pytest.mark.parametrize("prec", PRECS)
+def test_linear_gelu(dev, prec):
     from pope_amd import ops
     a, w, b = _rand(300, 384, seed=8), _rand(1536, 384, seed=9, scale=384 ** -0.5), _rand(1536, seed=10)
     want = F.gelu(F.linear(a, w, b))
-    got = ops.linear(a.to(dev), w.to(dev), b.to(dev), epilogue=ops.EPI_BIAS_GELU)
+    got = ops.linear(a.to(dev), w.to(dev), b.to(dev), epilogue=ops.EPI_BIAS_GELU, precision=prec)
     _close(got, want, atol=1e-5, rtol=1e-5)
 
 
-def test_linear_layerscale_residual_inplace(dev):
+@pytest.mark.parametrize("prec", PRECS)
+def test_linear_layerscale_residual_inplace(dev, prec):
     from pope_amd import ops
     a, w, b = _rand(300, 1536, seed=11), _rand(384, 1536, seed=12, scale=1536 ** -0.5), _rand(384, seed=13)
     gamma, res = 0.3 + 0.1 * _rand(384, seed=14), _rand(300, 384, seed=15)
     want = res + F.linear(a, w, b) * gamma
     x = res.to(dev).clone()
-    got = ops.linear(a.to(dev), w.to(dev), b.to(dev), epilogue=ops.EPI_BIAS_LS_RES, gamma=gamma.to(dev), res=x, out=x)
+    got = ops.linear(a.to(dev), w.to(dev), b.to(dev), epilogue=ops.EPI_BIAS_LS_RES, gamma=gamma.to(dev), res=x, out=x,
+                     precision=prec)
     assert got.data_ptr() == x.data_ptr()
     _close(got, want, atol=1e-5, rtol=1e-5)
 

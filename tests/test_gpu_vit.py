@@ -11,11 +11,14 @@ pytestmark = pytest.mark.gpu
 ATOL = 2e-4
 
 
-@pytest.fixture(scope="module")
-def model(hip_lib, sd0):
+@pytest.fixture(scope="module", params=["f16x3", "f32"])
+def model(hip_lib, sd0, request):
+    """Both arithmetic modes of the Linear layers are held to the same tolerances."""
     from pope_amd.dinov2_utils import load_dinov2_model
     assert torch.cuda.is_available()
-    return load_dinov2_model(state_dict=sd0).to("cuda:0")
+    m = load_dinov2_model(state_dict=sd0).to("cuda:0")
+    m.precision = request.param
+    return m
 
 
 @pytest.mark.parametrize("name", ["vit_196", "vit_224", "vit_476x630"])
