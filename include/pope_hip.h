@@ -64,6 +64,8 @@ int pope_patch_embed_f32(const float* img, const float* proj_w, const float* pos
 /* Attention.forward core — attention.py:51-59: qkv[B,N,3,heads,64] -> out[B,N,heads*64],
  * softmax((q*0.125) k^T) v. */
 int pope_attention_f32(const float* qkv, float* out, int B, int N, int heads, void* stream);
+/* Same with an explicit POPE_PREC_* (pope_attention_f32 == POPE_PREC_F32_MFMA). */
+int pope_attention_prec_f32(const float* qkv, float* out, int B, int N, int heads, int precision, void* stream);
 
 /* F.cosine_similarity(ref[1,D], fea[P,D], dim=1, eps) — eval_linemod_json.py:94. */
 int pope_cls_cosine_f32(const float* ref, const float* fea, int P, int D, float eps, float* scores,
@@ -87,7 +89,7 @@ typedef struct pope_vit_weights {
     const float* patch_w;                 /* patch_embed.proj.weight flattened [dim, 3*patch^2] */
     const float *norm_w, *norm_b;         /* final norm                                         */
     const pope_vit_block_weights* blocks_host; /* HOST array [depth] of device-pointer structs  */
-    int precision;                        /* POPE_PREC_* of the Linear layers                   */
+    int precision;                        /* POPE_PREC_* of the Linear layers and of attention  */
 } pope_vit_weights;
 
 size_t pope_vit_workspace_bytes(int B, int ntok, int dim, int hidden);

@@ -1,0 +1,257 @@
+// Flash-style multi-head attention on the f16 matrix cores with error-compensated operands
+// ("f16x3": x = hi + lo, three v_mfma_f32_32x32x16_f16 per product block, fp32 accumulate).
+// Same contract as attention_f32.hip (attention.py:49-62: qkv[B,N,3,H,64] fp32 -> out[B,N,H*64]
+// fp32), same orientation: S^T = K.Q^T (16 keys of one query per lane), O^T += V^T.P^T with the
+// score registers converted in place into the B operand of the second product.
+//
+// Why: on gfx950 the f32 MFMA runs on the VALU lanes (157 TF/s, softmax VALU work is paid in full
+// on top); the f16 MFMA has 16x the rate on a separate pipe, so 3 MFMAs per product are 5.3x faster
+// and the softmax overlaps.  Accuracy: hi+lo carries 22 significand bits; Q is pre-scaled to the
+// log2 domain, P is computed as 2^(s - m + 10) (the 2^10 cancels in O / l) so that every probability
+// down to 1e-4 keeps a normal-range lo half; measured error of the output is at the level of the
+// fp32 chain (tests/test_gpu_ops.py).  Range contract: |q|,|k|,|v| < 65504.
+#include "common.h"
+#include "kernels.h"
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+constexpr int HD = 64, KT = 64, QB = 128;
+constexpr int KST = 72;   // K plane row stride (halves): 144 B = 9 x 16 B (odd) -> ds_read_b128 rows conflict-free
+constexpr int VST = 96;   // V plane row stride (halves): 192 B -> the 4 rows of a ds_read_b64_tr_b16 block hit disjoint banks
+constexpr int K_PLANE = KT * KST, V_PLANE = KT * VST;
+constexpr size_t X3_ATTN_LDS_BYTES = size_t(2) * (K_PLANE + V_PLANE) * sizeof(_Float16);  // 43 008 B
+constexpr int OST = 68;   // epilogue staging row (floats)
+static_assert(size_t(QB) * OST * sizeof(float) <= X3_ATTN_LDS_BYTES, "O^T transpose staging must fit");
+
+__device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void split4(f32x4 v, f16x4& hi, f16x4& lo) {
+    hi = __builtin_convertvector(v, f16x4);
+    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
+}
+__device__ __forceinline__ f16x8 cat(f16x4 a, f16x4 b) { return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+__global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                             int N, int heads) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Kh = reinterpret_cast<_Float16*>(smem);
+    _Float16* Kl = Kh + K_PLANE;
+    _Float16* Vh = Kl + K_PLANE;
+    _Float16* Vl = Vh + V_PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_qb = (N + QB - 1) / QB;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);  // query blocks of one (image, head) share an XCD's L2
+    const int bh = logical / n_qb, head = bh % heads, b = bh / heads, q0 = (logical - bh * n_qb) * QB;
+    const int D = heads * HD, rs = 3 * D;
+    const float* base = qkv + size_t(b) * N * rs;
+    const int koff = D + head * HD;
+
+    // Q^T fragments (B operand of S^T = K.Q^T): lane (r,h) holds Q[q = r][d = 16kg + 8h + j], scaled by
+    // head_dim^-0.5 * log2(e) so that the scores leave the MFMA in the log2 domain.
+    constexpr float QSCALE = 0.125f * 1.44269504088896340736f;
+    f16x8 qh[4], ql[4];
+    {
+        const int qrow = q0 + wave * 32 + r;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if (qrow < N) {
+                const float* p = base + size_t(qrow) * rs + head * HD + 16 * kg + 8 * h;
+                v0 = *reinterpret_cast<const f32x4*>(p);
+                v1 = *reinterpret_cast<const f32x4*>(p + 4);
+            }
+            f16x4 h0, l0, h1, l1;
+            split4(v0 * QSCALE, h0, l0);
+            split4(v1 * QSCALE, h1, l1);
+            qh[kg] = cat(h0, h1);
+            ql[kg] = cat(l0, l1);
+        }
+    }
+
+    // K/V staging: bounds-checked buffer loads (keys >= N read as zeros), split into hi/lo planes on
+    // the way into LDS (row-major [key][d]; V is consumed through the transposing LDS read).
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, unsigned(N) * unsigned(rs) * 4u, 0x00020000);
+    const int srow = tid >> 4, scol = (tid & 15) * 4;
+    unsigned kvoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kvoff[i] = (unsigned(srow + 16 * i) * unsigned(rs) + scol + koff) * 4u;
+    const unsigned tile_bytes = unsigned(KT) * unsigned(rs) * 4u, v_delta = unsigned(D) * 4u;
+    f32x4 rk[4], rv[4];
+    auto load_kv = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, kvoff[i], kt * tile_bytes, 0));
+            rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, kvoff[i] + v_delta, kt * tile_bytes, 0));
+        }
+    };
+    auto store_kv = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f16x4 hi, lo;
+            split4(rk[i], hi, lo);
+            *reinterpret_cast<f16x4*>(Kh + (srow + 16 * i) * KST + scol) = hi;
+            *reinterpret_cast<f16x4*>(Kl + (srow + 16 * i) * KST + scol) = lo;
+            split4(rv[i], hi, lo);
+            *reinterpret_cast<f16x4*>(Vh + (srow + 16 * i) * VST + scol) = hi;
+            *reinterpret_cast<f16x4*>(Vl + (srow + 16 * i) * VST + scol) = lo;
+        }
+    };
+
+    // ds_read_b64_tr_b16 addressing for the V^T fragments (A operand of O^T += V^T.P^T): within a
+    // 16-lane group, lane 4q+p supplies row q, columns 4p..4p+3 of a 4-key x 16-d block and lane i
+    // receives column i (its d) of the 4 keys.  Block of lane l: keys 4*(l>>5) + q (+16s +8 +32u),
+    // d columns 16*((l>>4)&1) + 4p (+32dt).
+    const int tr_off = (4 * h + ((lane & 15) >> 2)) * VST + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto vfrag = [&](const _Float16* plane, int u, int s, int dt) {
+        const _Float16* p = plane + tr_off + (32 * u + 16 * s) * VST + 32 * dt;
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+        const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 8 * VST));
+        return cat(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, c));
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m_run = -INFINITY;   // running max (log2 domain)
+    f32x2 l_run = {0.f, 0.f};  // running sum of 2^10-scaled probabilities, two partial lanes
+
+    auto tile = [&](int kt, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        if (kt) __syncthreads();  // every wave is done with the previous K/V stage
+        store_kv();
+        __syncthreads();
+        if constexpr (!LAST) load_kv(kt + 1);
+
+        // ---- S^T = K . Q^T, two 32-key sub-tiles, 3 MFMAs per 16-wide d step --------------------
+        f32x16 s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+        const _Float16* kb_h = Kh + r * KST + 8 * h;
+        const _Float16* kb_l = Kl + r * KST + 8 * h;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const f16x8 k0h = *reinterpret_cast<const f16x8*>(kb_h + 16 * kg);
+            const f16x8 k0l = *reinterpret_cast<const f16x8*>(kb_l + 16 * kg);
+            const f16x8 k1h = *reinterpret_cast<const f16x8*>(kb_h + 32 * KST + 16 * kg);
+            const f16x8 k1l = *reinterpret_cast<const f16x8*>(kb_l + 32 * KST + 16 * kg);
+            s0 = mfma_f16(k0l, qh[kg], s0);
+            s1 = mfma_f16(k1l, qh[kg], s1);
+            s0 = mfma_f16(k0h, ql[kg], s0);
+            s1 = mfma_f16(k1h, ql[kg], s1);
+            s0 = mfma_f16(k0h, qh[kg], s0);
+            s1 = mfma_f16(k1h, qh[kg], s1);
+        }
+        if constexpr (LAST) {  // mask the padded keys of the last tile
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kt * KT + mfma32_row(i, h);
+                if (key >= N) s0[i] = -INFINITY;
+                if (key + 32 >= N) s1[i] = -INFINITY;
+            }
+        }
+        // ---- online softmax in registers (log2 domain; p' = 2^(s - m + 10)) ------------------------
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));  // XDL write -> asm VALU read wait states
+        float mt = vmax3(s0[0], s1[0], s0[1]);
+#pragma unroll
+        for (int i = 1; i < 15; ++i) mt = vmax3(mt, s1[i], s0[i + 1]);
+        mt = vmax3(mt, s1[15], s1[15]);
+        mt = __builtin_fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = __builtin_fmaxf(m_run, mt);
+        if (__any(m_new > m_run)) {  // rescale only when some row's max moved (exact: alpha == 1 otherwise)
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run = l_run * alpha;
+            o0 *= alpha;
+            o1 *= alpha;
+        }
+        m_run = m_new;
+        const float mshift = m_new - 10.0f;
+        f32x2 ls = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            s0[i] = __builtin_amdgcn_exp2f(s0[i] - mshift);
+            s0[i + 1] = __builtin_amdgcn_exp2f(s0[i + 1] - mshift);
+            s1[i] = __builtin_amdgcn_exp2f(s1[i] - mshift);
+            s1[i + 1] = __builtin_amdgcn_exp2f(s1[i + 1] - mshift);
+            ls += f32x2{s0[i], s0[i + 1]} + f32x2{s1[i], s1[i + 1]};
+        }
+        l_run += ls;
+
+        // ---- O^T += V^T . P^T: score registers 8s..8s+7 of sub-tile u are the B fragment of k-step (u,s)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f32x4 p0, p1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p0[e] = (u ? s1 : s0)[8 * s + e];
+                    p1[e] = (u ? s1 : s0)[8 * s + 4 + e];
+                }
+                f16x4 h0, l0, h1, l1;
+                split4(p0, h0, l0);
+                split4(p1, h1, l1);
+                const f16x8 ph = cat(h0, h1), pl = cat(l0, l1);
+                const f16x8 v0h = vfrag(Vh, u, s, 0), v0l = vfrag(Vl, u, s, 0);
+                const f16x8 v1h = vfrag(Vh, u, s, 1), v1l = vfrag(Vl, u, s, 1);
+                o0 = mfma_f16(v0l, ph, o0);
+                o1 = mfma_f16(v1l, ph, o1);
+                o0 = mfma_f16(v0h, pl, o0);
+                o1 = mfma_f16(v1h, pl, o1);
+                o0 = mfma_f16(v0h, ph, o0);
+                o1 = mfma_f16(v1h, ph, o1);
+            }
+    };
+
+    const int nkt = (N + KT - 1) / KT;
+    load_kv(0);
+    for (int kt = 0; kt + 1 < nkt; ++kt) tile(kt, std::false_type{});
+    tile(nkt - 1, std::true_type{});
+    __syncthreads();  // the stage is free: reuse it for the O^T transpose
+
+    // Normalise (the 2^10 of p' cancels), transpose O^T through LDS, store whole 256-B head rows.
+    const float l_half = l_run[0] + l_run[1];
+    const float inv = 1.0f / (l_half + __shfl_xor(l_half, 32));
+    float* Os = smem + (wave * 32) * OST;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = o0[4 * g4 + e] * inv; c[e] = o1[4 * g4 + e] * inv; }
+        *reinterpret_cast<f32x4*>(&Os[r * OST + 8 * g4 + 4 * h]) = a;
+        *reinterpret_cast<f32x4*>(&Os[r * OST + 32 + 8 * g4 + 4 * h]) = c;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int lr = (lane >> 4) + 4 * i, c4 = (lane & 15) * 4;
+        const int qrow = q0 + wave * 32 + lr;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&Os[lr * OST + c4]);
+        if (qrow < N) *reinterpret_cast<f32x4*>(out + (size_t(b) * N + qrow) * D + head * HD + c4) = v;
+    }
+}
+
+}  // namespace
+
+int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || heads <= 0 || size_t(B) * heads * ((N + QB - 1) / QB) > 0x7fffffffull) return POPE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return POPE_ERR_ARG;
+    if (size_t(N) * 3 * heads * HD * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
+    const dim3 grid(unsigned((N + QB - 1) / QB) * heads * B);
+    hipLaunchKernelGGL(attn_f16x3_kernel, grid, dim3(256), X3_ATTN_LDS_BYTES, stream, qkv, out, N, heads);
+    return pope_check_launch();
+}

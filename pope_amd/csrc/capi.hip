@@ -104,7 +104,13 @@ int pope_patch_embed_f32(const float* img, const float* proj_w, const float* pos
 }
 
 int pope_attention_f32(const float* qkv, float* out, int B, int N, int heads, void* stream) {
+    return pope_attention_prec_f32(qkv, out, B, N, heads, POPE_PREC_F32_MFMA, stream);
+}
+
+int pope_attention_prec_f32(const float* qkv, float* out, int B, int N, int heads, int precision, void* stream) {
     if (!qkv || !out) return POPE_ERR_ARG;
+    if (precision == POPE_PREC_F16X3) return pope_launch_attention_f16x3(qkv, out, B, N, heads, static_cast<hipStream_t>(stream));
+    if (precision != POPE_PREC_F32_MFMA) return POPE_ERR_ARG;
     return pope_launch_attention_f32(qkv, out, B, N, heads, static_cast<hipStream_t>(stream));
 }
 
@@ -158,7 +164,7 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
         POPE_MARK(POPE_K_GEMM_QKV);
         if ((rc = pope_linear_prec_f32(xn, k.qkv_w, k.qkv_b, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, prec, stream))) return rc;
         POPE_MARK(POPE_K_ATTENTION);
-        if ((rc = pope_launch_attention_f32(qkv, att, B, ntok, w->heads, stream))) return rc;
+        if ((rc = pope_attention_prec_f32(qkv, att, B, ntok, w->heads, prec, stream))) return rc;
         POPE_MARK(POPE_K_GEMM_PROJ);
         if ((rc = pope_linear_prec_f32(att, k.proj_w, k.proj_b, x, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, prec, stream))) return rc;
         // x = x + ls2(mlp(norm2(x)))                                       block.py:106

@@ -57,13 +57,14 @@ def patch_embed(img, proj_w, posb, patch):
     return out
 
 
-def attention(qkv, heads):
+def attention(qkv, heads, precision="f32"):
     """softmax((q/8) k^T) v on qkv[B,N,3*heads*64] (attention.py:51-59)."""
     qkv = _f32c(qkv, "attention")
     b, n, d3 = qkv.shape
     assert d3 == 3 * heads * 64
     out = torch.empty(b, n, heads * 64, device=qkv.device, dtype=torch.float32)
-    check(_lib.lib().pope_attention_f32(ptr(qkv), ptr(out), b, n, heads, stream_of(qkv.device)), "pope_attention_f32")
+    check(_lib.lib().pope_attention_prec_f32(ptr(qkv), ptr(out), b, n, heads, _lib.PRECISIONS[precision],
+                                             stream_of(qkv.device)), "pope_attention_prec_f32")
     return out
 
 

@@ -115,19 +115,35 @@ def test_patch_embed_rejects_non_multiple(dev, sd0):
         model(torch.zeros(1, 3, 480, 640, device=dev))
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B,N,heads", [(1, 1, 6), (2, 31, 6), (2, 64, 6), (1, 197, 6), (2, 257, 6), (1, 1531, 6),
                                         (1, 130, 12)])
-def test_attention(dev, B, N, heads):
+def test_attention(dev, B, N, heads, prec):
     from pope_amd import ops
     D = heads * 64
     qkv = _rand(B, N, 3 * D, seed=30 + N, scale=1.5)
     q, k, v = qkv.reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
     want = (((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B, N, D)
-    got = ops.attention(qkv.to(dev), heads)
+    got = ops.attention(qkv.to(dev), heads, precision=prec)
     _close(got, want, atol=2e-5, rtol=1e-5)
 
 
-def test_attention_online_softmax_rescale_branch(dev):
+@pytest.mark.parametrize("prec", PRECS)
+def test_attention_error_vs_fp64(dev, prec):
+    # both arithmetic modes against an fp64 reference on the bench shape's key count (N = 1531)
+    from pope_amd import ops
+    B, N, heads = 1, 1531, 6
+    qkv = _rand(B, N, 3 * heads * 64, seed=77, scale=1.5)
+    q, k, v = qkv.double().reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    want = (((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B, N, heads * 64)
+    got = ops.attention(qkv.to(dev), heads, precision=prec).cpu().double()
+    err = float((got - want).abs().max())
+    print(f"attention {prec}: max |err| vs fp64 = {err:.2e} (|out| max {float(want.abs().max()):.2f})")
+    assert err < 2e-5
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_attention_online_softmax_rescale_branch(dev, prec):
     # force the running max to jump at a late key tile (spiked key), so the rescale of O and l is
     # exercised with a large factor (guide rule: a rare data-dependent branch needs its own test)
     from pope_amd import ops
@@ -138,7 +154,7 @@ def test_attention_online_softmax_rescale_branch(dev):
     t[0, 290, 1] = t[0, 70, 0] * -40.0  # and a strongly negative one
     q, k, v = t.permute(2, 0, 3, 1, 4)
     want = (((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B, N, heads * 64)
-    got = ops.attention(qkv.to(dev), heads)
+    got = ops.attention(qkv.to(dev), heads, precision=prec)
     _close(got, want, atol=2e-5, rtol=1e-5)
 
 
