@@ -29,7 +29,13 @@ H_IMG, W_IMG, PATCH = 476, 630, 14
 NTOK = 1 + (H_IMG // PATCH) * (W_IMG // PATCH)  # 1531
 DIM, HEADS, HIDDEN, DEPTH = 384, 6, 1536, 12
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16), same guide
 PEAK_HBM_GBS = 8000.0
+# arithmetic modes of the contractions (pope_hip.h POPE_PREC_*): MFMA dtype, dense peak, MFMA FLOPs
+# executed per algorithmic FLOP (f16x3 = three partial products per product block)
+PRECISION_INFO = {"f16x3": ("f16x3 (fp32 operands split hi+lo into f16, 3 MFMAs per product, fp32 accumulate)",
+                            PEAK_F16_MFMA_TFLOPS, 3),
+                  "f32": ("f32 (v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS, 1)}
 
 
 def flops_per_image(np_=NTOK - 1):
@@ -111,6 +117,8 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--precision", choices=sorted(PRECISION_INFO), default="f16x3",
+                    help="arithmetic of the Linear layers and attention (both are held to the same parity tests)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,6 +137,8 @@ def main():
     from pope_amd.pipeline import PairPipeline, gather_counts
 
     model = load_dinov2_model(state_dict=synth.synthetic_state_dict(seed=0)).to(device)
+    model.precision = args.precision
+    dtype_name, peak_tflops, mfma_factor = PRECISION_INFO[args.precision]
     pipe = PairPipeline(model, chunk=args.chunk)
     from pope_amd.profiling import KernelProfiler
     n_chunks = -(-args.pairs // args.chunk) * 2  # ViT launch sequences per step
@@ -168,7 +178,7 @@ def main():
         "metric": "image-pairs/s (DINOv2-S/14 extract+match, 640x480)",
         "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": "extract(2 x DINOv2-S/14 @476x630 centre crop of 640x480, 1531 tokens) + dense "
                                "dual-softmax mutual-NN match (1530x1530x384) per pair",
                    "pairs_per_gpu_per_step": args.pairs, "vit_chunk_images": args.chunk,
@@ -194,14 +204,16 @@ def main():
         except (OSError, ValueError):
             pass
         result["roofline"] = {
-            "kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": peak_tflops,
+            "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak_tflops, 4), "traffic": traffic,
+            "mfma_flops_per_algorithmic_flop": mfma_factor,
+            "frac_of_executed_mfma_flops": round(mfma_factor * dom["tflops"] / peak_tflops, 4),
             "algorithmic_bytes_per_launch": kernel_bytes(dom["kernel"], args.chunk),
             "flops_per_launch": dom["flops_per_launch"], "avg_ms_per_launch": dom["avg_ms"],
             "launches_timed": dom["launches"],
             "note": "algorithmic FLOPs / HIP-event duration of every launch of this kernel inside the timed "
-                    "region (events on the launch stream); peak = dense f32-in/f32-acc MFMA "
-                    "(v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md",
+                    "region (events on the launch stream); peak = dense MFMA peak of the MFMA dtype "
+                    "(MI355X_MICROARCH.md); f16x3 executes 3 MFMA FLOPs per algorithmic FLOP",
         }
         result["kernels"] = [{k: t[k] for k in ("kernel", "launches", "avg_ms", "ms_per_step", "tflops", "gbs")}
                              for t in tab]
