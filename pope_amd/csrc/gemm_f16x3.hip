@@ -7,10 +7,11 @@
 //
 // Same interface, tiling (128x128x32, 4 waves x 2x2 32x32 tiles), buffer-load register staging,
 // LDS-transposed epilogue and epilogue modes as gemm_f32.hip; fp32 in, fp32 out.
-// The lo halves are stored scaled by 2^11 (lo' = f16((x - hi) * 2048), same magnitude as hi, so they
-// never fall into the f16 subnormal range) and the two cross terms hi.lo' + lo'.hi accumulate in
-// their own fp32 accumulator, folded in as acc + 2^-11 * cross in the epilogue: the representation
-// stays relative (2^-22) for every |x| in [6.1e-5, 65504).  Range contract: |operand| < 65504.
+// Both operands are multiplied by a power of two before the split (activations 2^3, weights 2^8 by
+// default; exact, undone by one exact multiply in the epilogue) so that the lo half of every
+// element that matters stays in the f16 normal range: the representation is relative (2^-22) for
+// |a| >= 2^-6 and |w| >= 2^-11 and absolute (2^-28 resp. 2^-33) below — far under the fp32 chain's
+// own rounding for O(1) activations.  Range contract: |a| < 8188, |w| < 255 (f16 max / scale).
 #include "gemm_core.h"
 #include "kernels.h"
 
@@ -23,16 +24,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PL_ST = 40;                       // plane row stride in halves: 80 B = 5 x 16 B (odd) -> b128 reads conflict-free
 constexpr int PLANE = 128 * PL_ST;              // halves per plane (128 rows)
-constexpr size_t X3_LDS_BYTES = size_t(4) * PLANE * sizeof(_Float16);  // A hi, A lo, W hi, W lo = 40 KB
+constexpr int STAGE = 4 * PLANE;                // A hi, A lo, W hi, W lo
+// TWO LDS stages of 40 KB: exactly two workgroups per CU (2 x 80 KB = the CU's 160 KB).  The
+// split + ds_write of K-step t+1 goes to the other stage while the MFMAs of K-step t run, so a
+// K-step has ONE barrier and its VALU / LDS-write / global-load work sits between its MFMAs (the f16
+// MFMA has its own pipe; co-resident waves run in lockstep and would not hide it for each other).
+constexpr size_t X3_LDS_BYTES = size_t(2) * STAGE * sizeof(_Float16);
 static_assert(X3_LDS_BYTES >= size_t(4) * 32 * EPI_ST * sizeof(float), "epilogue staging must fit");
 
-__device__ __forceinline__ void split(f32x4 v, f16x4& hi, f16x4& lo) {
+constexpr float A_SCALE = 8.0f, W_SCALE = 256.0f;  // powers of two: exact
+
+__device__ __forceinline__ void split(f32x4 v, float scale, f16x4& hi, f16x4& lo) {
+    v = v * scale;
     hi = __builtin_convertvector(v, f16x4);                          // v_cvt_pk_f16_f32 x2 (RNE)
-#ifdef X3_FAKE_SPLIT  // timing experiment only: drop the lo computation (wrong results)
-    lo = hi;
-#else
-    lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * 2048.0f, f16x4);
-#endif
+    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
 }
 
 __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
@@ -41,13 +46,12 @@ __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
 
 __device__ __forceinline__ float gelu_erf_scalar(float x);  // defined below (shared formula with gemm_f32.hip)
 
-template <int EPI>
+// LAB is 0 in the product; scripts/x3_lab.cpp times ablations: bit0 = no global loads after the
+// prologue, bit1 = no split / LDS writes after the first stage, bit2 = no MFMAs.
+template <int EPI, int LAB = 0>
 __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_kernel(const GemmParams g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    _Float16* Ah = reinterpret_cast<_Float16*>(smem);
-    _Float16* Al = Ah + PLANE;
-    _Float16* Wh = Al + PLANE;
-    _Float16* Wl = Wh + PLANE;
+    _Float16* lds = reinterpret_cast<_Float16*>(smem);
 
     const int tiles_n = (g.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -57,45 +61,48 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_kernel(const GemmPar
     const int srow = tid >> 3, scol = (tid & 7) * 4;
 
     const BufferLoader la(g.A, g.M, g.lda, m0), lw(g.W, g.N, g.ldw, n0);
-    // Two register staging sets, prefetch distance TWO K-steps: a K-step's 24 MFMAs last only
-    // ~770 cycles, far less than an L2/HBM round trip, so the loads of K-step t+2 are issued as soon
-    // as the registers of K-step t have been split into LDS (out-of-range K-steps read zeros).
-    f32x4 ra0[4], rw0[4], ra1[4], rw1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra0[i] = la.load(i, 0);
-        rw0[i] = lw.load(i, 0);
-    }
     const int nk = g.K / BK;
+    // One register staging set.  During K-step t it holds K-step t+1 (split into the other LDS stage)
+    // and is then refilled with K-step t+2, which has a whole K-step plus a barrier to arrive.
+    f32x4 ra[4], rw[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        ra1[i] = la.load(i, nk > 1 ? BK : 0);
-        rw1[i] = lw.load(i, nk > 1 ? BK : 0);
+        ra[i] = la.load(i, 0);
+        rw[i] = lw.load(i, 0);
     }
-    f32x16 acc[2][2], cross[2][2];  // hi.hi | hi.lo' + lo'.hi (scaled by 2^11)
+    f32x16 acc[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc[mi][ni][i] = 0.f; cross[mi][ni][i] = 0.f; }
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-    const int a_off = (wm * 64 + r) * PL_ST + 8 * h, w_off = (wn * 64 + r) * PL_ST + 8 * h;
-    auto kstep = [&](int kt, f32x4 (&ra)[4], f32x4 (&rw)[4]) {
-        __syncthreads();  // every wave is done reading the previous stage
+    auto stage_write = [&](int st) {
+        _Float16* Ah = lds + st * STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f16x4 hi, lo;
             const int o = (srow + 32 * i) * PL_ST + scol;
-            split(ra[i], hi, lo);
+            split(ra[i], A_SCALE, hi, lo);
             *reinterpret_cast<f16x4*>(Ah + o) = hi;
-            *reinterpret_cast<f16x4*>(Al + o) = lo;
-            split(rw[i], hi, lo);
-            *reinterpret_cast<f16x4*>(Wh + o) = hi;
-            *reinterpret_cast<f16x4*>(Wl + o) = lo;
+            *reinterpret_cast<f16x4*>(Ah + PLANE + o) = lo;
+            split(rw[i], W_SCALE, hi, lo);
+            *reinterpret_cast<f16x4*>(Ah + 2 * PLANE + o) = hi;
+            *reinterpret_cast<f16x4*>(Ah + 3 * PLANE + o) = lo;
         }
-        __syncthreads();
-        if (kt + 2 < nk) {
+    };
+    const int a_off = (wm * 64 + r) * PL_ST + 8 * h, w_off = 2 * PLANE + (wn * 64 + r) * PL_ST + 8 * h;
+    // K-step kt: MFMAs on stage kt&1; meanwhile the staged registers (K-step kt+1) are split into the
+    // other stage and then refilled with K-step kt+2.
+    // MODE 2: steady state (split + refill), 1: split only (K-step kt+2 does not exist), 0: last K-step.
+    // The variants are separate straight-line bodies so that each K-step is ONE basic block and the
+    // scheduler can interleave its MFMAs with the split / LDS / load instructions.
+    auto kstep = [&](int kt, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const _Float16* S = lds + (kt & 1) * STAGE;
+        if constexpr (MODE >= 1 && !(LAB & 2)) stage_write((kt + 1) & 1);
+        if constexpr (MODE == 2 && !(LAB & 1)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 ra[i] = la.load(i, (kt + 2) * BK);
@@ -107,30 +114,58 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_kernel(const GemmPar
             f16x8 ah[2], al[2], wh[2], wl[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                ah[t] = *reinterpret_cast<const f16x8*>(Ah + a_off + t * 32 * PL_ST + kg * 16);
-                al[t] = *reinterpret_cast<const f16x8*>(Al + a_off + t * 32 * PL_ST + kg * 16);
-                wh[t] = *reinterpret_cast<const f16x8*>(Wh + w_off + t * 32 * PL_ST + kg * 16);
-                wl[t] = *reinterpret_cast<const f16x8*>(Wl + w_off + t * 32 * PL_ST + kg * 16);
+                ah[t] = *reinterpret_cast<const f16x8*>(S + a_off + t * 32 * PL_ST + kg * 16);
+                al[t] = *reinterpret_cast<const f16x8*>(S + PLANE + a_off + t * 32 * PL_ST + kg * 16);
+                wh[t] = *reinterpret_cast<const f16x8*>(S + w_off + t * 32 * PL_ST + kg * 16);
+                wl[t] = *reinterpret_cast<const f16x8*>(S + PLANE + w_off + t * 32 * PL_ST + kg * 16);
             }
             // accumulators hold C^T (rows over n): A-operand = W fragment, B-operand = A fragment
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    cross[mi][ni] = mfma_f16(wl[ni], ah[mi], cross[mi][ni]);
-                    cross[mi][ni] = mfma_f16(wh[ni], al[mi], cross[mi][ni]);
-                    acc[mi][ni] = mfma_f16(wh[ni], ah[mi], acc[mi][ni]);
+                    if constexpr (LAB & 4) {
+                        acc[mi][ni][0] += float(wl[ni][0]) + float(ah[mi][0]) + float(wh[ni][1]) + float(al[mi][1]);
+                    } else {
+                        acc[mi][ni] = mfma_f16(wl[ni], ah[mi], acc[mi][ni]);  // small terms first
+                        acc[mi][ni] = mfma_f16(wh[ni], al[mi], acc[mi][ni]);
+                        acc[mi][ni] = mfma_f16(wh[ni], ah[mi], acc[mi][ni]);
+                    }
                 }
         }
+        // 24 MFMAs : ~130 VALU (split) : 16 LDS reads : 16 LDS writes : 8 buffer loads — pin an even mix
+        // (LLVM sched groups: 0x8 MFMA, 0x2 VALU, 0x100 DS read, 0x200 DS write, 0x20 VMEM read)
+        if constexpr (MODE >= 1 && LAB == 0) {
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (i >= 4 && i < 20) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if (MODE == 2 && i >= 12 && i < 20) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        __syncthreads();  // stage (kt+1)&1 is published, stage kt&1 is free
     };
-    for (int kt = 0; kt < nk; kt += 2) {
-        kstep(kt, ra0, rw0);
-        if (kt + 1 < nk) kstep(kt + 1, ra1, rw1);
+
+    stage_write(0);  // K-step 0
+    if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = la.load(i, BK);
+            rw[i] = lw.load(i, BK);
+        }
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 2 < nk) kstep(kt, std::integral_constant<int, 2>{});
+        else if (kt + 1 < nk) kstep(kt, std::integral_constant<int, 1>{});
+        else kstep(kt, std::integral_constant<int, 0>{});
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = acc[mi][ni] + cross[mi][ni] * (1.0f / 2048.0f);
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = acc[mi][ni] * (1.0f / (A_SCALE * W_SCALE));
 
     epilogue_rows(acc, smem, [&](int tr, int tc, f32x4 v) {
         const int row = m0 + tr, col = n0 + tc;
@@ -170,12 +205,33 @@ __device__ __forceinline__ float gelu_erf_scalar(float x) {
 
 template <int EPI>
 int launch(const GemmParams& g, hipStream_t stream) {
+    static bool attr_set = false;  // 80 KB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f16x3_kernel<EPI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(X3_LDS_BYTES)) != hipSuccess)
+            return POPE_ERR_LAUNCH;
+        attr_set = true;
+    }
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     hipLaunchKernelGGL((gemm_nt_f16x3_kernel<EPI>), dim3(tiles), dim3(THREADS), X3_LDS_BYTES, stream, g);
     return pope_check_launch();
 }
 
 }  // namespace
+
+// lab entry (not part of the C ABI): launch an ablated variant
+int pope_lab_gemm_f16x3(const GemmParams& g, int lab, hipStream_t stream) {
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+#define POPE_LAB_CASE(L)                                                                                          \
+    case L:                                                                                                       \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f16x3_kernel<EPI_BIAS, L>),                     \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, int(X3_LDS_BYTES));                       \
+        hipLaunchKernelGGL((gemm_nt_f16x3_kernel<EPI_BIAS, L>), dim3(tiles), dim3(THREADS), X3_LDS_BYTES, stream, g); \
+        break;
+    switch (lab) { POPE_LAB_CASE(1) POPE_LAB_CASE(2) POPE_LAB_CASE(3) POPE_LAB_CASE(4) POPE_LAB_CASE(5) POPE_LAB_CASE(6) default: return POPE_ERR_ARG; }
+#undef POPE_LAB_CASE
+    return pope_check_launch();
+}
 
 bool pope_gemm_f16x3_supported(const GemmParams& g) {
     return g.epilogue != EPI_POSB && (g.K % BK) == 0 && size_t(g.M + BM) * g.lda * 4 < (size_t(1) << 32) &&

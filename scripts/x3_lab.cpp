@@ -4,6 +4,10 @@
 #include <cstdio>
 #include <vector>
 
+int pope_lab_gemm_f16x3(const GemmParams& g, int lab, hipStream_t stream);
+static int g_lab = 0;
+static int lab_fn(const GemmParams& g, hipStream_t s) { return pope_lab_gemm_f16x3(g, g_lab, s); }
+
 static float timeit(int (*fn)(const GemmParams&, hipStream_t), const GemmParams& g) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     float best = 1e9;
@@ -49,6 +53,10 @@ int main() {
                 }
             err[v] = e; ref_rms = sqrt(rr / ((256 / 5 + 1) * (sh.N / 7 + 1)));
         }
+        float tl[7] = {0};
+        for (int l = 1; l <= 6; ++l) { g_lab = l; tl[l] = timeit(lab_fn, g); }
+        printf("   ablations (ms): noload %.3f | nosplit/ldswrite %.3f | mfma+ldsread only %.3f | nomfma %.3f | nomfma+noload %.3f | nomfma+nosplit %.3f\n",
+               tl[1], tl[2], tl[3], tl[4], tl[5], tl[6]);
         printf("%s f32-mfma %.3f ms (%.1f TF) maxerr %.2e | f16x3 %.3f ms (%.1f TF-eq) maxerr %.2e | out rms %.2f\n", sh.name, t[0],
                gf / t[0], err[0], t[1], gf / t[1], err[1], ref_rms);
     }
