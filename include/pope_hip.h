@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define POPE_ABI_VERSION 1
+#define POPE_ABI_VERSION 2
 
 enum {
     POPE_EPI_BIAS = 0,        /* C = A.W^T + bias                         nn.Linear                     */
@@ -54,6 +54,25 @@ int pope_linear_f32(const float* A, const float* W, const float* bias, float* C,
 int pope_linear_prec_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
                          int epilogue, const float* gamma, const float* res, int precision, void* stream);
 
+/* f16x3 "planes": a tensor X[rows, cols] (cols % 32 == 0) kept as f16 halves with X * scale = hi + lo
+ * (scale a power of two: POPE_PLANES_ACT_SCALE for activations, POPE_PLANES_W_SCALE for weights), laid
+ * out row-major with 2*cols halves per row and, per 32-column chunk, the 32 hi halves followed by the
+ * 32 lo halves (one 128-byte cache line per row and GEMM K-step):
+ *     half_offset(row, col, plane) = row*2*cols + (col/32)*64 + plane*32 + col%32.
+ * Producers split once (LayerNorm, the GELU epilogue, the weight loader) so that the f16x3 GEMM
+ * stages MFMA-ready operands with no conversion work in its K loop. */
+#define POPE_PLANES_ACT_SCALE 8.0f
+#define POPE_PLANES_W_SCALE 256.0f
+int pope_split_planes_f32(const float* src, void* planes, int rows, int cols, float scale, void* stream);
+/* nn.Linear on planes: A planes [M,K], W planes [N,K]; output either fp32 C[M,N] (c_planes == NULL) or
+ * activation planes [M,N] (C == NULL; not for POPE_EPI_BIAS_LS_RES).  K % 32 == 0, K >= 64. */
+int pope_linear_planes_f32(const void* a_planes, const void* w_planes, const float* bias, float* C,
+                           void* c_planes, int M, int N, int K, int epilogue, const float* gamma,
+                           const float* res, void* stream);
+/* LayerNorm written as activation planes [rows, dim]. */
+int pope_layernorm_planes_f32(const float* x, const float* weight, const float* bias, void* y_planes,
+                              int rows, int dim, float eps, void* stream);
+
 /* PatchEmbed.forward + prepare_tokens_with_masks — patch_embed.py:69-82,
  * vision_transformer.py:191-200.  img[B,3,H,W]; proj_w[dim, 3*patch*patch];
  * posb[ntok, dim] = {cls_token + pos[0]; conv_bias + pos[n]} with pos already interpolated to
@@ -82,6 +101,9 @@ typedef struct pope_vit_block_weights {   /* state-dict keys blocks.{i}.*  (devi
     const float *fc1_w, *fc1_b;           /* mlp.fc1.weight [hidden,dim]                      */
     const float *fc2_w, *fc2_b;           /* mlp.fc2.weight [dim,hidden]                      */
     const float *ls2;
+    /* optional (POPE_PREC_F16X3): weight planes [out][in] (layout above), scale POPE_PLANES_W_SCALE;
+     * NULL -> the layer splits its fp32 weights on the fly */
+    const void *qkv_wp, *fc1_wp, *fc2_wp;
 } pope_vit_block_weights;
 
 typedef struct pope_vit_weights {

@@ -18,7 +18,7 @@ c_ll_p = C.POINTER(C.c_longlong)
 class VitBlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
-        "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+        "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "qkv_wp", "fc1_wp", "fc2_wp")]
 
 
 class VitWeights(C.Structure):
@@ -29,6 +29,7 @@ class VitWeights(C.Structure):
 
 # name -> (restype, argtypes); every symbol declared in include/pope_hip.h
 PREC_F32_MFMA, PREC_F16X3 = 0, 1
+PLANES_ACT_SCALE, PLANES_W_SCALE = 8.0, 256.0
 PRECISIONS = {"f32": PREC_F32_MFMA, "f16x3": PREC_F16X3}
 
 PROTOTYPES = {
@@ -37,6 +38,9 @@ PROTOTYPES = {
     "pope_layernorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pope_linear_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 3),
     "pope_linear_prec_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 2 + [C.c_int, C.c_void_p]),
+    "pope_split_planes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "pope_linear_planes_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p] * 3),
+    "pope_layernorm_planes_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pope_patch_embed_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "pope_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pope_attention_prec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -85,7 +89,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.pope_abi_version() != 1:
+        if handle.pope_abi_version() != 2:
             raise RuntimeError("libpope_hip.so ABI version mismatch")
         _lib = handle
     return _lib
@@ -98,6 +102,23 @@ class PopeHipError(RuntimeError):
 def check(status, what):
     if status != 0:
         raise PopeHipError(f"{what}: {lib().pope_error_string(status).decode()} (status {status})")
+
+
+def to_planes(t, scale):
+    """torch restatement of the planes layout (pope_hip.h): [rows, cols] fp32 -> f16 [rows, cols/32, 2, 32]
+    with t*scale = hi + lo, hi = RNE f16."""
+    ts = t.detach().float() * scale
+    hi = ts.half()
+    lo = (ts - hi.float()).half()
+    r, c = t.shape
+    import torch
+    return torch.stack([hi.view(r, c // 32, 32), lo.view(r, c // 32, 32)], dim=2).contiguous()
+
+
+def from_planes(pl, scale):
+    """inverse of to_planes (fp32)."""
+    r = pl.shape[0]
+    return (pl[:, :, 0].float() + pl[:, :, 1].float()).reshape(r, -1) / scale
 
 
 def ptr(t):

@@ -21,13 +21,17 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-constexpr int HD = 64, KT = 64, QB = 128;
+constexpr int HD = 64, KT = 64;
+constexpr int WAVES = 8;          // 8 waves x 32 queries share each K/V tile: half the L2 -> LDS traffic and half the
+constexpr int QB = 32 * WAVES;    // per-wave K/V split work of a 4-wave block (the kernel is L2-bandwidth sensitive)
+constexpr int NT = 64 * WAVES;
 constexpr int KST = 72;   // K plane row stride (halves): 144 B = 9 x 16 B (odd) -> ds_read_b128 rows conflict-free
 constexpr int VST = 96;   // V plane row stride (halves): 192 B -> the 4 rows of a ds_read_b64_tr_b16 block hit disjoint banks
 constexpr int K_PLANE = KT * KST, V_PLANE = KT * VST;
-constexpr size_t X3_ATTN_LDS_BYTES = size_t(2) * (K_PLANE + V_PLANE) * sizeof(_Float16);  // 43 008 B
+constexpr size_t X3_ATTN_STAGE_BYTES = size_t(2) * (K_PLANE + V_PLANE) * sizeof(_Float16);  // 43 008 B
 constexpr int OST = 68;   // epilogue staging row (floats)
-static_assert(size_t(QB) * OST * sizeof(float) <= X3_ATTN_LDS_BYTES, "O^T transpose staging must fit");
+constexpr size_t X3_ATTN_EPI_BYTES = size_t(32) * 8 * OST * sizeof(float);  // O^T transpose staging, 32 rows per wave
+
 
 __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -43,7 +47,7 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
     return d;
 }
 
-__global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__(NT, 2) void attn_f16x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                              int N, int heads) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Kh = reinterpret_cast<_Float16*>(smem);
@@ -86,29 +90,30 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const float* __restr
     // the way into LDS (row-major [key][d]; V is consumed through the transposing LDS read).
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, unsigned(N) * unsigned(rs) * 4u, 0x00020000);
+    constexpr int RPP = NT / 16, NP = KT / RPP;  // staging rows per pass, passes per 64-key tile
     const int srow = tid >> 4, scol = (tid & 15) * 4;
-    unsigned kvoff[4];
+    unsigned kvoff[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) kvoff[i] = (unsigned(srow + 16 * i) * unsigned(rs) + scol + koff) * 4u;
+    for (int i = 0; i < NP; ++i) kvoff[i] = (unsigned(srow + RPP * i) * unsigned(rs) + scol + koff) * 4u;
     const unsigned tile_bytes = unsigned(KT) * unsigned(rs) * 4u, v_delta = unsigned(D) * 4u;
-    f32x4 rk[4], rv[4];
+    f32x4 rk[NP], rv[NP];
     auto load_kv = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             rk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, kvoff[i], kt * tile_bytes, 0));
             rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, kvoff[i] + v_delta, kt * tile_bytes, 0));
         }
     };
     auto store_kv = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             f16x4 hi, lo;
             split4(rk[i], hi, lo);
-            *reinterpret_cast<f16x4*>(Kh + (srow + 16 * i) * KST + scol) = hi;
-            *reinterpret_cast<f16x4*>(Kl + (srow + 16 * i) * KST + scol) = lo;
+            *reinterpret_cast<f16x4*>(Kh + (srow + RPP * i) * KST + scol) = hi;
+            *reinterpret_cast<f16x4*>(Kl + (srow + RPP * i) * KST + scol) = lo;
             split4(rv[i], hi, lo);
-            *reinterpret_cast<f16x4*>(Vh + (srow + 16 * i) * VST + scol) = hi;
-            *reinterpret_cast<f16x4*>(Vl + (srow + 16 * i) * VST + scol) = lo;
+            *reinterpret_cast<f16x4*>(Vh + (srow + RPP * i) * VST + scol) = hi;
+            *reinterpret_cast<f16x4*>(Vl + (srow + RPP * i) * VST + scol) = lo;
         }
     };
 
@@ -252,6 +257,14 @@ int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int 
     if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return POPE_ERR_ARG;
     if (size_t(N) * 3 * heads * HD * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
     const dim3 grid(unsigned((N + QB - 1) / QB) * heads * B);
-    hipLaunchKernelGGL(attn_f16x3_kernel, grid, dim3(256), X3_ATTN_LDS_BYTES, stream, qkv, out, N, heads);
+    constexpr size_t lds = X3_ATTN_STAGE_BYTES > X3_ATTN_EPI_BYTES ? X3_ATTN_STAGE_BYTES : X3_ATTN_EPI_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                int(lds)) != hipSuccess)
+            return POPE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_f16x3_kernel, grid, dim3(NT), lds, stream, qkv, out, N, heads);
     return pope_check_launch();
 }

@@ -88,6 +88,29 @@ int pope_linear_prec_f32(const float* A, const float* W, const float* bias, floa
     return pope_launch_gemm_nt_f32(g, static_cast<hipStream_t>(stream));
 }
 
+int pope_split_planes_f32(const float* src, void* planes, int rows, int cols, float scale, void* stream) {
+    return pope_launch_split_planes(src, planes, rows, cols, scale, static_cast<hipStream_t>(stream));
+}
+
+int pope_linear_planes_f32(const void* a_planes, const void* w_planes, const float* bias, float* C, void* c_planes,
+                           int M, int N, int K, int epilogue, const float* gamma, const float* res, void* stream) {
+    if (epilogue < 0 || epilogue > POPE_EPI_BIAS_LS_RES) return POPE_ERR_ARG;
+    GemmParams g = {};
+    g.a_pl = a_planes; g.w_pl = w_planes;
+    g.bias = bias; g.C = C; g.c_pl = c_planes;
+    g.lda = K; g.ldw = K; g.ldc = N;
+    g.M = M; g.N = N; g.K = K;
+    g.epilogue = epilogue;
+    g.gamma = gamma; g.res = res; g.ldres = N;
+    return pope_launch_gemm_nt_f16x3_planes(g, static_cast<hipStream_t>(stream));
+}
+
+int pope_layernorm_planes_f32(const float* x, const float* weight, const float* bias, void* y_planes, int rows, int dim,
+                              float eps, void* stream) {
+    if (!x || !weight || !bias) return POPE_ERR_ARG;
+    return pope_launch_layernorm_planes(x, dim, weight, bias, y_planes, rows, dim, eps, static_cast<hipStream_t>(stream));
+}
+
 int pope_patch_embed_f32(const float* img, const float* proj_w, const float* posb, float* tokens, int B, int H,
                          int W, int patch, int dim, void* stream) {
     if (!img || !proj_w || !posb || !tokens || B <= 0 || patch <= 0 || H % patch || W % patch) return POPE_ERR_ARG;
@@ -159,21 +182,47 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
     for (int i = 0; i < w->depth; ++i) {
         const pope_vit_block_weights& k = w->blocks_host[i];
         // x = x + ls1(attn(norm1(x)))                                      block.py:105
+        const bool planes = prec == POPE_PREC_F16X3 && k.qkv_wp && k.fc1_wp && k.fc2_wp && dim % 32 == 0 && dim >= 64;
+        void* xn_pl = xn;    // planes alias the xn / fc1 buffers: 2 x f16 per element = the fp32 footprint
+        void* hid_pl = hid;
         POPE_MARK(POPE_K_LAYERNORM);
-        if ((rc = pope_launch_layernorm_f32(x, dim, k.norm1_w, k.norm1_b, xn, dim, rows, dim, eps, stream))) return rc;
+        if (planes) {
+            if ((rc = pope_launch_layernorm_planes(x, dim, k.norm1_w, k.norm1_b, xn_pl, rows, dim, eps, stream))) return rc;
+        } else {
+            if ((rc = pope_launch_layernorm_f32(x, dim, k.norm1_w, k.norm1_b, xn, dim, rows, dim, eps, stream))) return rc;
+        }
         POPE_MARK(POPE_K_GEMM_QKV);
-        if ((rc = pope_linear_prec_f32(xn, k.qkv_w, k.qkv_b, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, prec, stream))) return rc;
+        if (planes) {
+            if ((rc = pope_linear_planes_f32(xn_pl, k.qkv_wp, k.qkv_b, qkv, nullptr, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr,
+                                             stream))) return rc;
+        } else {
+            if ((rc = pope_linear_prec_f32(xn, k.qkv_w, k.qkv_b, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, prec, stream))) return rc;
+        }
         POPE_MARK(POPE_K_ATTENTION);
         if ((rc = pope_attention_prec_f32(qkv, att, B, ntok, w->heads, prec, stream))) return rc;
         POPE_MARK(POPE_K_GEMM_PROJ);
         if ((rc = pope_linear_prec_f32(att, k.proj_w, k.proj_b, x, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, prec, stream))) return rc;
         // x = x + ls2(mlp(norm2(x)))                                       block.py:106
         POPE_MARK(POPE_K_LAYERNORM);
-        if ((rc = pope_launch_layernorm_f32(x, dim, k.norm2_w, k.norm2_b, xn, dim, rows, dim, eps, stream))) return rc;
+        if (planes) {
+            if ((rc = pope_launch_layernorm_planes(x, dim, k.norm2_w, k.norm2_b, xn_pl, rows, dim, eps, stream))) return rc;
+        } else {
+            if ((rc = pope_launch_layernorm_f32(x, dim, k.norm2_w, k.norm2_b, xn, dim, rows, dim, eps, stream))) return rc;
+        }
         POPE_MARK(POPE_K_GEMM_FC1);
-        if ((rc = pope_linear_prec_f32(xn, k.fc1_w, k.fc1_b, hid, rows, hidden, dim, EPI_BIAS_GELU, nullptr, nullptr, prec, stream))) return rc;
+        if (planes) {
+            if ((rc = pope_linear_planes_f32(xn_pl, k.fc1_wp, k.fc1_b, nullptr, hid_pl, rows, hidden, dim, EPI_BIAS_GELU, nullptr,
+                                             nullptr, stream))) return rc;
+        } else {
+            if ((rc = pope_linear_prec_f32(xn, k.fc1_w, k.fc1_b, hid, rows, hidden, dim, EPI_BIAS_GELU, nullptr, nullptr, prec, stream))) return rc;
+        }
         POPE_MARK(POPE_K_GEMM_FC2);
-        if ((rc = pope_linear_prec_f32(hid, k.fc2_w, k.fc2_b, x, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x, prec, stream))) return rc;
+        if (planes) {
+            if ((rc = pope_linear_planes_f32(hid_pl, k.fc2_wp, k.fc2_b, x, nullptr, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x,
+                                             stream))) return rc;
+        } else {
+            if ((rc = pope_linear_prec_f32(hid, k.fc2_w, k.fc2_b, x, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x, prec, stream))) return rc;
+        }
         for (int t = 0; t < n_taps; ++t)
             if (tap_blocks_host[t] == i && tap_out_host[t]) {
                 POPE_MARK(POPE_K_TAP_COPY);

@@ -187,6 +187,187 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_kernel(const GemmPar
     });
 }
 
+// ---- planes kernel -----------------------------------------------------------------------------
+// Operands arrive already split (f16 hi/lo planes written once by their producer: LayerNorm, the GELU
+// epilogue, the weight loader), so the K loop is loads -> ds_write_b128 -> ds_read_b128 -> MFMA with
+// no VALU work at all; the epilogue can emit planes for the next GEMM.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// Persistent: two workgroups per CU walk the tile list (logical id = xcd_remap(blockIdx) + i*grid:
+// an XCD keeps whole A row panels in its L2) and treat the K-steps of consecutive tiles as ONE
+// stream through the double-buffered LDS: while the last K-step of a tile runs, the first stage of
+// the next tile is already being loaded and written, so neither the load latency of a tile's first
+// K-steps nor a workgroup re-launch sits between tiles (with K = 384 a tile is only 12 K-steps:
+// prologue + epilogue + launch gap were half of a one-tile workgroup's lifetime).
+template <int EPI, bool OUT_PLANES>
+__global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const GemmParams g, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* lds = reinterpret_cast<_Float16*>(smem);
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    // Staging: a row's K-step is 128 contiguous bytes in memory ([32 hi | 32 lo] halves) = eight 16-byte
+    // pieces = eight consecutive lanes -> whole cache lines.  Thread -> rows prow + 32 i (i < 4), piece pc
+    // (plane pc>>2, 16-byte column pc&3).  The row order is permuted so that the rows written by one
+    // 8-lane ds_write_b128 group (two rows x one plane... consecutive slots) are 4 apart: their 64-byte
+    // bank ranges are 16 banks apart with the 80-byte row stride (conflict-free).
+    const int slot = tid >> 3, pc = tid & 7;
+    const int prow = ((slot >> 1) & 3) + 4 * (slot & 1) + 8 * (slot >> 3);  // bijection on 0..31
+    const int lds_piece = (pc >> 2) * PLANE + 8 * (pc & 3);
+    const int nk = g.K / BK;  // >= 2 (launcher)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, unsigned(g.M) * unsigned(g.lda) * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, unsigned(g.N) * unsigned(g.ldw) * 4u, 0x00020000);
+    u32x4 st[8];  // A rows 0..3, W rows 0..3
+    // loads of K-step kt of the tile at (m0, n0): byte offset = row * 4 ld + kt * 128 + pc * 16
+    auto load_stage = [&](int m0, int n0, int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned va = unsigned(m0 + prow + 32 * i) * unsigned(g.lda) * 4u + pc * 16u;
+            const unsigned vw = unsigned(n0 + prow + 32 * i) * unsigned(g.ldw) * 4u + pc * 16u;
+            st[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, kt * 128, 0);
+            st[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, kt * 128, 0);
+        }
+    };
+    auto write_stage = [&](int s) {
+        _Float16* S = lds + s * STAGE + lds_piece;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(S + (prow + 32 * i) * PL_ST) = st[i];
+            *reinterpret_cast<u32x4*>(S + 2 * PLANE + (prow + 32 * i) * PL_ST) = st[4 + i];
+        }
+    };
+    const int a_off = (wm * 64 + r) * PL_ST + 8 * h, w_off = 2 * PLANE + (wn * 64 + r) * PL_ST + 8 * h;
+    f32x16 acc[2][2];
+    auto mfma_step = [&](int s) {
+        const _Float16* S = lds + s * STAGE;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            f16x8 ah[2], al[2], wh[2], wl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const f16x8*>(S + a_off + t * 32 * PL_ST + kg * 16);
+                al[t] = *reinterpret_cast<const f16x8*>(S + PLANE + a_off + t * 32 * PL_ST + kg * 16);
+                wh[t] = *reinterpret_cast<const f16x8*>(S + w_off + t * 32 * PL_ST + kg * 16);
+                wl[t] = *reinterpret_cast<const f16x8*>(S + PLANE + w_off + t * 32 * PL_ST + kg * 16);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = mfma_f16(wl[ni], ah[mi], acc[mi][ni]);  // small terms first
+                    acc[mi][ni] = mfma_f16(wh[ni], al[mi], acc[mi][ni]);
+                    acc[mi][ni] = mfma_f16(wh[ni], ah[mi], acc[mi][ni]);
+                }
+        }
+    };
+
+    const int stride = gridDim.x;
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= n_tiles) return;
+#ifdef X3_SKEW
+    {   // experiment: spread the workgroups over four phases of a tile period so that their epilogue
+        // store bursts do not coincide
+        const int phase = (blockIdx.x >= gridDim.x / 2) ? 1 : 0;  // second dispatch wave = the co-resident workgroups
+        for (int i = 0; i < phase * X3_SKEW; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+    // global K-step counter `ks` selects the LDS stage (ks & 1) across tile seams
+    int ks = 0;
+    {
+        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+        load_stage(m0, n0, 0);
+        write_stage(0);
+        load_stage(m0, n0, 1);
+    }
+    __syncthreads();
+#ifdef X3_STAMPS
+    int tcount = 0;
+#define X3_TSTAMP(slot)                                                                                  \
+    do {                                                                                                 \
+        unsigned long long t_;                                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
+        if (g.posb && tid == 0 && blockIdx.x < 64 && tcount < 4)                                         \
+            reinterpret_cast<unsigned long long*>(const_cast<float*>(g.posb))[(blockIdx.x * 4 + tcount) * 16 + (slot)] = t_; \
+    } while (0)
+#else
+#define X3_TSTAMP(slot) do { } while (0)
+#endif
+    for (; tile < n_tiles; tile += stride) {
+        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+        const int nt = tile + stride;
+        X3_TSTAMP(0);
+        const bool has_next = nt < n_tiles;
+        const int nm0 = has_next ? (nt / tiles_n) * BM : 0, nn0 = has_next ? (nt % tiles_n) * BN : 0;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+        // K-steps 0 .. nk-3: registers hold K-step kt+1 -> other stage; refill with kt+2
+        for (int kt = 0; kt + 2 < nk; ++kt, ++ks) {
+            write_stage((ks + 1) & 1);
+            load_stage(m0, n0, kt + 2);
+            mfma_step(ks & 1);
+            __syncthreads();
+            if (kt < 10) X3_TSTAMP(1 + kt);
+        }
+        // K-step nk-2: registers hold K-step nk-1; refill with the NEXT tile's K-step 0
+        write_stage((ks + 1) & 1);
+        if (has_next) load_stage(nm0, nn0, 0);
+        mfma_step(ks & 1);
+        __syncthreads();
+        ++ks;
+        // K-step nk-1 (last of this tile): publish the next tile's K-step 0, fetch its K-step 1
+        if (has_next) {
+            write_stage((ks + 1) & 1);
+            load_stage(nm0, nn0, 1);
+        }
+        mfma_step(ks & 1);
+        ++ks;
+        X3_TSTAMP(12);
+        // the epilogue stages through the LDS stage the last K-step just used, which is free once every
+        // wave has passed the barrier inside epilogue_rows; the next tile's K-step 0 sits in the other one
+        float* epi = reinterpret_cast<float*>(lds + ((ks + 1) & 1) * STAGE);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = acc[mi][ni] * (1.0f / (A_SCALE * W_SCALE));
+        epilogue_rows(acc, epi, [&](int tr, int tc, f32x4 v) {
+            const int row = m0 + tr, col = n0 + tc;
+            if (row >= g.M || col >= g.N) return;
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+            if (g.bias) bias = *reinterpret_cast<const f32x4*>(g.bias + col);
+            if constexpr (EPI == EPI_BIAS) {
+                v = v + bias;
+            } else if constexpr (EPI == EPI_BIAS_GELU) {
+                v = v + bias;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf_scalar(v[e]);
+            } else {
+                const f32x4 gamma = *reinterpret_cast<const f32x4*>(g.gamma + col);
+                const f32x4 res = *reinterpret_cast<const f32x4*>(g.res + size_t(row) * g.ldres + col);
+                v = res + (v + bias) * gamma;
+            }
+            if constexpr (OUT_PLANES) {
+                f16x4 hi, lo;
+                split(v, A_SCALE, hi, lo);
+                _Float16* o = static_cast<_Float16*>(g.c_pl) + size_t(row) * 2 * g.ldc + (col >> 5) * 64 + (col & 31);
+                *reinterpret_cast<f16x4*>(o) = hi;
+                *reinterpret_cast<f16x4*>(o + 32) = lo;
+            } else {
+                *reinterpret_cast<f32x4*>(g.C + size_t(row) * g.ldc + col) = v;
+            }
+        });
+        __syncthreads();  // epilogue staging is drained before the next tile's K-step 1 is written over it
+        X3_TSTAMP(13);
+#ifdef X3_STAMPS
+        ++tcount;
+#endif
+    }
+}
+
 // exact-erf GELU, Abramowitz-Stegun 7.1.26 form (see gemm_f32.hip:gelu_erf2 for the derivation)
 __device__ __forceinline__ float gelu_erf_scalar(float x) {
     constexpr float P = 0.3275911f * 0.70710678118654752440f;
@@ -224,13 +405,47 @@ int pope_lab_gemm_f16x3(const GemmParams& g, int lab, hipStream_t stream) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
 #define POPE_LAB_CASE(L)                                                                                          \
     case L:                                                                                                       \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f16x3_kernel<EPI_BIAS, L>),                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f16x3_kernel<EPI_BIAS, L>),                   \
                             hipFuncAttributeMaxDynamicSharedMemorySize, int(X3_LDS_BYTES));                       \
         hipLaunchKernelGGL((gemm_nt_f16x3_kernel<EPI_BIAS, L>), dim3(tiles), dim3(THREADS), X3_LDS_BYTES, stream, g); \
         break;
     switch (lab) { POPE_LAB_CASE(1) POPE_LAB_CASE(2) POPE_LAB_CASE(3) POPE_LAB_CASE(4) POPE_LAB_CASE(5) POPE_LAB_CASE(6) default: return POPE_ERR_ARG; }
 #undef POPE_LAB_CASE
     return pope_check_launch();
+}
+
+template <int EPI, bool OUT_PLANES>
+int launch_planes(const GemmParams& g, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f16x3_planes_kernel<EPI, OUT_PLANES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(X3_LDS_BYTES)) != hipSuccess)
+            return POPE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    const int slots = 2 * pope_cu_count();  // two resident workgroups per CU (2 x 80 KB LDS)
+    hipLaunchKernelGGL((gemm_nt_f16x3_planes_kernel<EPI, OUT_PLANES>), dim3(tiles < slots ? tiles : slots), dim3(THREADS),
+                       X3_LDS_BYTES, stream, g, tiles);
+    return pope_check_launch();
+}
+
+int pope_launch_gemm_nt_f16x3_planes(const GemmParams& g, hipStream_t stream) {
+    static_assert(A_SCALE == K_PLANES_ACT_SCALE && W_SCALE == K_PLANES_W_SCALE, "plane scales");
+    if (g.M <= 0 || g.N <= 0 || g.K < 2 * BK || (g.K % BK) || (g.N & 3) || (g.ldc & 3) || (g.lda & 7) || (g.ldw & 7)) return POPE_ERR_ARG;
+    if (!g.a_pl || !g.w_pl || (g.lda & 31) || (g.ldw & 31)) return POPE_ERR_ARG;
+    if (size_t(g.M + BM) * g.lda * 4 >= (size_t(1) << 32) || size_t(g.N + BN) * g.ldw * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
+    const bool out_planes = g.c_pl != nullptr;
+    if (out_planes ? (g.ldc & 31) != 0 : !g.C) return POPE_ERR_ARG;
+    switch (g.epilogue) {
+        case EPI_BIAS: return out_planes ? launch_planes<EPI_BIAS, true>(g, stream) : launch_planes<EPI_BIAS, false>(g, stream);
+        case EPI_BIAS_GELU:
+            return out_planes ? launch_planes<EPI_BIAS_GELU, true>(g, stream) : launch_planes<EPI_BIAS_GELU, false>(g, stream);
+        case EPI_BIAS_LS_RES:
+            if (!g.gamma || !g.res || out_planes) return POPE_ERR_ARG;
+            return launch_planes<EPI_BIAS_LS_RES, false>(g, stream);
+    }
+    return POPE_ERR_ARG;
 }
 
 bool pope_gemm_f16x3_supported(const GemmParams& g) {

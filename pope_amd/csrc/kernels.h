@@ -21,6 +21,15 @@ struct GemmParams {
     const float* gamma;  // [N]      (EPI_BIAS_LS_RES)
     const float* res;    // [M,ldres](EPI_BIAS_LS_RES; may alias C)
     int ldres;
+    // f16x3 "planes" operands (gemm_f16x3.hip, planes kernel): a tensor X[rows, ld] kept as two f16
+    // planes with X = (hi + lo) / scale (power-of-two scale: activations 8, weights 256).  The planes
+    // kernel needs a_pl and w_pl; when c_pl is set its epilogue writes planes (scale 8) instead of fp32 C.
+    // Layout of a planes tensor [rows, ld]: row-major, 2*ld halves per row, per 32-column chunk the
+    // 32 hi halves then the 32 lo halves (128 contiguous bytes = one cache line per row and K-step):
+    //   offset(row, col, plane) = row*2*ld + (col>>5)*64 + plane*32 + (col&31).
+    const void* a_pl;
+    const void* w_pl;
+    void* c_pl;
     // patch-embed gather (EPI_POSB)
     const float* posb;   // [ntok, N]: row 0 = cls_token + pos[0]; row n = conv bias + pos[n]
     int ntok, img_h, img_w, patch, grid_w;
@@ -30,6 +39,15 @@ int pope_launch_gemm_nt_f32(const GemmParams& g, hipStream_t stream);
 
 // Same contract on the f16 matrix cores with error-compensated operands (gemm_f16x3.hip).
 bool pope_gemm_f16x3_supported(const GemmParams& g);
+// Planes variant: W (and optionally A / C) as pre-split f16 planes, no splitting in the K loop.
+int pope_launch_gemm_nt_f16x3_planes(const GemmParams& g, hipStream_t stream);
+constexpr float K_PLANES_ACT_SCALE = 8.0f, K_PLANES_W_SCALE = 256.0f;  // == POPE_PLANES_*_SCALE of pope_hip.h
+
+// y = LayerNorm(x) written as f16 planes (scale POPE_PLANES_ACT_SCALE), [rows, dim] halves each.
+int pope_launch_layernorm_planes(const float* x, int ldx, const float* w, const float* b, void* y_pl,
+                                 int rows, int dim, float eps, hipStream_t stream);
+// Generic fp32 [rows, ld] -> planes converter (ld % 32 == 0).
+int pope_launch_split_planes(const float* src, void* pl, int rows, int ld, float scale, hipStream_t stream);
 int pope_launch_gemm_nt_f16x3(const GemmParams& g, hipStream_t stream);
 
 // y[r,:] = LayerNorm(x[r,:]) * w + b over `dim` (multiple of 128, <= 2048), eps inside the sqrt.

@@ -46,7 +46,93 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// Same LayerNorm, output as f16 hi/lo planes for the f16x3 GEMMs (y*scale = hi + lo): the split is
+// done once here, in an HBM-bound kernel with idle VALU, instead of per K-step in every GEMM tile.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __restrict__ x, int ldx,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ b,
+                                                                _Float16* __restrict__ ypl,
+                                                                int rows, float eps, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + size_t(row) * ldx;
+    f32x2 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const f32x2*>(xr + i * 128 + lane * 2);
+        s += v[i][0] + v[i][1];
+    }
+    constexpr float inv_d = 1.0f / float(NV * 128);
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float d0 = v[i][0] - mean, d1 = v[i][1] - mean;
+        q += d0 * d0 + d1 * d1;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+    _Float16* yr = ypl + size_t(row) * (2 * NV * 128);  // planes layout: per 32-column chunk [32 hi | 32 lo]
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 128 + lane * 2;
+        const f32x2 ww = *reinterpret_cast<const f32x2*>(w + c);
+        const f32x2 bb = *reinterpret_cast<const f32x2*>(b + c);
+        f32x2 y;
+        y[0] = ((v[i][0] - mean) * rstd * ww[0] + bb[0]) * scale;
+        y[1] = ((v[i][1] - mean) * rstd * ww[1] + bb[1]) * scale;
+        const f16x2 hi = __builtin_convertvector(y, f16x2);
+        const f16x2 lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x2), f16x2);
+        *reinterpret_cast<f16x2*>(yr + (c >> 5) * 64 + (c & 31)) = hi;
+        *reinterpret_cast<f16x2*>(yr + (c >> 5) * 64 + 32 + (c & 31)) = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, _Float16* __restrict__ pl,
+                                                            size_t n2, int ld, float scale) {
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n2; i += size_t(gridDim.x) * 256) {
+        const size_t e = 2 * i, row = e / ld;
+        const int c = int(e - row * ld);
+        const f32x2 y = *reinterpret_cast<const f32x2*>(src + e) * scale;
+        const f16x2 h = __builtin_convertvector(y, f16x2);
+        _Float16* o = pl + row * 2 * ld + (c >> 5) * 64 + (c & 31);
+        *reinterpret_cast<f16x2*>(o) = h;
+        *reinterpret_cast<f16x2*>(o + 32) = __builtin_convertvector(y - __builtin_convertvector(h, f32x2), f16x2);
+    }
+}
+
 }  // namespace
+
+int pope_launch_layernorm_planes(const float* x, int ldx, const float* w, const float* b, void* y_pl,
+                                 int rows, int dim, float eps, hipStream_t stream) {
+    if (rows <= 0 || dim <= 0 || (dim & 127) || dim > 2048 || (ldx & 1) || !y_pl) return POPE_ERR_ARG;
+    const dim3 grid((rows + 3) / 4), block(256);
+    _Float16* ypl = static_cast<_Float16*>(y_pl);
+#define POPE_LNP_CASE(NV)                                                                                    \
+    case NV:                                                                                                 \
+        hipLaunchKernelGGL(layernorm_planes_kernel<NV>, grid, block, 0, stream, x, ldx, w, b, ypl, rows, eps,    \
+                           K_PLANES_ACT_SCALE);                                                           \
+        break;
+    switch (dim / 128) {
+        POPE_LNP_CASE(1) POPE_LNP_CASE(2) POPE_LNP_CASE(3) POPE_LNP_CASE(4) POPE_LNP_CASE(6) POPE_LNP_CASE(8)
+        POPE_LNP_CASE(12) POPE_LNP_CASE(16)
+        default: return POPE_ERR_ARG;
+    }
+#undef POPE_LNP_CASE
+    return pope_check_launch();
+}
+
+int pope_launch_split_planes(const float* src, void* pl, int rows, int ld, float scale, hipStream_t stream) {
+    if (!src || !pl || rows <= 0 || ld <= 0 || (ld & 31)) return POPE_ERR_ARG;
+    const size_t n2 = size_t(rows) * ld / 2;
+    const unsigned blocks = unsigned(n2 / 256 + 1 < 4096 ? n2 / 256 + 1 : 4096);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, static_cast<_Float16*>(pl), n2, ld, scale);
+    return pope_check_launch();
+}
 
 int pope_launch_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
                               int rows, int dim, float eps, hipStream_t stream) {

@@ -147,12 +147,21 @@ class DinoVisionTransformer(nn.Module):
             tensors.append(t)
             return t.data_ptr()
 
+        def planes(wt):
+            """f16 hi/lo planes of a Linear weight for the f16x3 GEMM (layout: pope_hip.h)."""
+            if self.precision != "f16x3" or not wt.is_cuda or wt.shape[1] % 32:
+                return None
+            pl = _lib.to_planes(wt, _lib.PLANES_W_SCALE)
+            tensors.append(pl)
+            return pl.data_ptr()
+
         blocks = (_lib.VitBlockWeights * self.n_blocks)()
         for i, b in enumerate(self.blocks):
             blocks[i] = _lib.VitBlockWeights(
                 P(b.norm1.weight), P(b.norm1.bias), P(b.attn.qkv.weight), P(b.attn.qkv.bias),
                 P(b.attn.proj.weight), P(b.attn.proj.bias), P(b.ls1.gamma), P(b.norm2.weight), P(b.norm2.bias),
-                P(b.mlp.fc1.weight), P(b.mlp.fc1.bias), P(b.mlp.fc2.weight), P(b.mlp.fc2.bias), P(b.ls2.gamma))
+                P(b.mlp.fc1.weight), P(b.mlp.fc1.bias), P(b.mlp.fc2.weight), P(b.mlp.fc2.bias), P(b.ls2.gamma),
+                planes(b.attn.qkv.weight), planes(b.mlp.fc1.weight), planes(b.mlp.fc2.weight))
         w = _lib.VitWeights(self.embed_dim, self.n_blocks, self.num_heads, self.patch_size,
                             self.blocks[0].mlp.fc1.weight.shape[0],
                             P(self.patch_embed.proj.weight.reshape(self.embed_dim, -1)),

@@ -168,3 +168,52 @@ def test_cls_cosine_and_top3(dev, golden_dir):
     assert np.array_equal(idx, fx["slot_index"])  # identical top-3 slot assignment
     z = ops.cls_cosine(torch.tensor([[1e-9, 0, 0]], device=dev), torch.tensor([[2e-9, 0, 0]], device=dev))
     assert abs(float(z) - 0.02) < 1e-6
+
+
+@pytest.mark.parametrize("epi", ["bias", "gelu_planes_out", "ls_res"])
+def test_linear_planes_kernel(dev, hip_lib, epi):
+    """f16x3 GEMM on pre-split planes (as LayerNorm / the GELU epilogue / the weight loader produce them),
+    through the C ABI, against fp64."""
+    import ctypes as C
+    from pope_amd import _lib
+    M, N, K = 700, 384, 1536
+    a, w, b = _rand(M, K, seed=61, scale=1.3), _rand(N, K, seed=62, scale=K ** -0.5), _rand(N, seed=63)
+    ap = _lib.to_planes(a, _lib.PLANES_ACT_SCALE).to(dev)
+    wp = _lib.to_planes(w, _lib.PLANES_W_SCALE).to(dev)
+    bd = b.to(dev)
+    lin = F.linear(a.double(), w.double(), b.double())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    if epi == "gelu_planes_out":
+        op = torch.empty(M, N // 32, 2, 32, dtype=torch.float16, device=dev)
+        assert hip_lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), None, P(op), M, N, K, 1, None, None, st) == 0
+        got, want = _lib.from_planes(op.cpu(), _lib.PLANES_ACT_SCALE), F.gelu(lin).float()
+    elif epi == "ls_res":
+        gamma, res = 0.3 + 0.1 * _rand(N, seed=64), _rand(M, N, seed=65)
+        x = res.to(dev).clone()
+        assert hip_lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(x), None, M, N, K, 2, P(gamma.to(dev)), P(x), st) == 0
+        got, want = x.cpu(), (res.double() + lin * gamma.double()).float()
+    else:
+        out = torch.empty(M, N, device=dev)
+        assert hip_lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(out), None, M, N, K, 0, None, None, st) == 0
+        got, want = out.cpu(), lin.float()
+    _close(got, want, atol=1e-5, rtol=1e-5)
+
+
+def test_layernorm_planes_and_split(dev, hip_lib):
+    import ctypes as C
+    from pope_amd import _lib
+    rows, dim = 333, 384
+    x = _rand(rows, dim, seed=71, scale=3.0) + 0.7
+    w, b = 1 + 0.1 * _rand(dim, seed=72), 0.1 * _rand(dim, seed=73)
+    want = F.layer_norm(x, (dim,), w, b, 1e-6)
+    yp = torch.empty(rows, dim // 32, 2, 32, dtype=torch.float16, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    assert hip_lib.pope_layernorm_planes_f32(P(x.to(dev)), P(w.to(dev)), P(b.to(dev)), P(yp), rows, dim, 1e-6, st) == 0
+    _close(_lib.from_planes(yp.cpu(), _lib.PLANES_ACT_SCALE), want, atol=3e-6)
+    # the device splitter == the torch formulation used for the weight planes (bit for bit)
+    src = _rand(1000, 64, seed=74, scale=0.05)
+    sp = torch.empty(1000, 2, 2, 32, dtype=torch.float16, device=dev)
+    assert hip_lib.pope_split_planes_f32(P(src.to(dev)), P(sp), 1000, 64, _lib.PLANES_W_SCALE, st) == 0
+    assert torch.equal(sp.cpu(), _lib.to_planes(src, _lib.PLANES_W_SCALE))
