@@ -218,18 +218,29 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     const int nk = g.K / BK;  // >= 2 (launcher)
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, unsigned(g.M) * unsigned(g.lda) * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, unsigned(g.N) * unsigned(g.ldw) * 4u, 0x00020000);
-    u32x4 st[8];  // A rows 0..3, W rows 0..3
-    // loads of K-step kt of the tile at (m0, n0): byte offset = row * 4 ld + kt * 128 + pc * 16
-    auto load_stage = [&](int m0, int n0, int kt) {
+    // K-steps of this workgroup's tiles form ONE stream (item = (tile, kt)); two register sets keep
+    // the loads of items s+2 and s+3 in flight while item s runs from LDS stage s&1 and item s+1 is
+    // written to the other stage: the CU has ~128 KB of loads outstanding, which is what it takes to
+    // cover the L2 round trip at this tile size (one set = 64 KB in flight measured ~23 B/clk/CU).
+    u32x4 r0[8], r1[8];  // A rows 0..3, W rows 0..3
+    const int stride = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, gridDim.x);
+    if (first >= n_tiles) return;
+    int ld_tile = first, ld_kt = 0;  // next stream item to load
+    auto load_next = [&](u32x4 (&st)[8]) {
+        if (ld_tile < n_tiles) {
+            const int m0 = (ld_tile / tiles_n) * BM, n0 = (ld_tile % tiles_n) * BN;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned va = unsigned(m0 + prow + 32 * i) * unsigned(g.lda) * 4u + pc * 16u;
-            const unsigned vw = unsigned(n0 + prow + 32 * i) * unsigned(g.ldw) * 4u + pc * 16u;
-            st[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, kt * 128, 0);
-            st[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, kt * 128, 0);
+            for (int i = 0; i < 4; ++i) {
+                const unsigned va = unsigned(m0 + prow + 32 * i) * unsigned(g.lda) * 4u + pc * 16u;
+                const unsigned vw = unsigned(n0 + prow + 32 * i) * unsigned(g.ldw) * 4u + pc * 16u;
+                st[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, ld_kt * 128, 0);
+                st[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, ld_kt * 128, 0);
+            }
+            if (++ld_kt == nk) { ld_kt = 0; ld_tile += stride; }
         }
     };
-    auto write_stage = [&](int s) {
+    auto write_stage = [&](int s, const u32x4 (&st)[8]) {
         _Float16* S = lds + s * STAGE + lds_piece;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -239,97 +250,37 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     };
     const int a_off = (wm * 64 + r) * PL_ST + 8 * h, w_off = 2 * PLANE + (wn * 64 + r) * PL_ST + 8 * h;
     f32x16 acc[2][2];
-    auto mfma_step = [&](int s) {
-        const _Float16* S = lds + s * STAGE;
-#pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-            f16x8 ah[2], al[2], wh[2], wl[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                ah[t] = *reinterpret_cast<const f16x8*>(S + a_off + t * 32 * PL_ST + kg * 16);
-                al[t] = *reinterpret_cast<const f16x8*>(S + PLANE + a_off + t * 32 * PL_ST + kg * 16);
-                wh[t] = *reinterpret_cast<const f16x8*>(S + w_off + t * 32 * PL_ST + kg * 16);
-                wl[t] = *reinterpret_cast<const f16x8*>(S + PLANE + w_off + t * 32 * PL_ST + kg * 16);
-            }
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    acc[mi][ni] = mfma_f16(wl[ni], ah[mi], acc[mi][ni]);  // small terms first
-                    acc[mi][ni] = mfma_f16(wh[ni], al[mi], acc[mi][ni]);
-                    acc[mi][ni] = mfma_f16(wh[ni], ah[mi], acc[mi][ni]);
-                }
-        }
-    };
-
-    const int stride = gridDim.x;
-    int tile = xcd_remap(blockIdx.x, gridDim.x);
-    if (tile >= n_tiles) return;
-#ifdef X3_SKEW
-    {   // experiment: spread the workgroups over four phases of a tile period so that their epilogue
-        // store bursts do not coincide
-        const int phase = (blockIdx.x >= gridDim.x / 2) ? 1 : 0;  // second dispatch wave = the co-resident workgroups
-        for (int i = 0; i < phase * X3_SKEW; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-    // global K-step counter `ks` selects the LDS stage (ks & 1) across tile seams
-    int ks = 0;
-    {
-        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-        load_stage(m0, n0, 0);
-        write_stage(0);
-        load_stage(m0, n0, 1);
-    }
-    __syncthreads();
-#ifdef X3_STAMPS
-    int tcount = 0;
-#define X3_TSTAMP(slot)                                                                                  \
-    do {                                                                                                 \
-        unsigned long long t_;                                                                           \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
-        if (g.posb && tid == 0 && blockIdx.x < 64 && tcount < 4)                                         \
-            reinterpret_cast<unsigned long long*>(const_cast<float*>(g.posb))[(blockIdx.x * 4 + tcount) * 16 + (slot)] = t_; \
-    } while (0)
-#else
-#define X3_TSTAMP(slot) do { } while (0)
-#endif
-    for (; tile < n_tiles; tile += stride) {
-        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-        const int nt = tile + stride;
-        X3_TSTAMP(0);
-        const bool has_next = nt < n_tiles;
-        const int nm0 = has_next ? (nt / tiles_n) * BM : 0, nn0 = has_next ? (nt % tiles_n) * BN : 0;
+    auto zero_acc = [&]() {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
-        // K-steps 0 .. nk-3: registers hold K-step kt+1 -> other stage; refill with kt+2
-        for (int kt = 0; kt + 2 < nk; ++kt, ++ks) {
-            write_stage((ks + 1) & 1);
-            load_stage(m0, n0, kt + 2);
-            mfma_step(ks & 1);
-            __syncthreads();
-            if (kt < 10) X3_TSTAMP(1 + kt);
+    };
+    struct Frags { f16x8 ah[2], al[2], wh[2], wl[2]; };
+    auto read_frags = [&](int s, int kg, Frags& f) {
+        const _Float16* S = lds + s * STAGE;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f.ah[t] = *reinterpret_cast<const f16x8*>(S + a_off + t * 32 * PL_ST + kg * 16);
+            f.al[t] = *reinterpret_cast<const f16x8*>(S + PLANE + a_off + t * 32 * PL_ST + kg * 16);
+            f.wh[t] = *reinterpret_cast<const f16x8*>(S + w_off + t * 32 * PL_ST + kg * 16);
+            f.wl[t] = *reinterpret_cast<const f16x8*>(S + PLANE + w_off + t * 32 * PL_ST + kg * 16);
         }
-        // K-step nk-2: registers hold K-step nk-1; refill with the NEXT tile's K-step 0
-        write_stage((ks + 1) & 1);
-        if (has_next) load_stage(nm0, nn0, 0);
-        mfma_step(ks & 1);
-        __syncthreads();
-        ++ks;
-        // K-step nk-1 (last of this tile): publish the next tile's K-step 0, fetch its K-step 1
-        if (has_next) {
-            write_stage((ks + 1) & 1);
-            load_stage(nm0, nn0, 1);
-        }
-        mfma_step(ks & 1);
-        ++ks;
-        X3_TSTAMP(12);
-        // the epilogue stages through the LDS stage the last K-step just used, which is free once every
-        // wave has passed the barrier inside epilogue_rows; the next tile's K-step 0 sits in the other one
-        float* epi = reinterpret_cast<float*>(lds + ((ks + 1) & 1) * STAGE);
+    };
+    auto mfma_frags = [&](const Frags& f) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                acc[mi][ni] = mfma_f16(f.wl[ni], f.ah[mi], acc[mi][ni]);  // small terms first
+                acc[mi][ni] = mfma_f16(f.wh[ni], f.al[mi], acc[mi][ni]);
+                acc[mi][ni] = mfma_f16(f.wh[ni], f.ah[mi], acc[mi][ni]);
+            }
+    };
+    auto epilogue = [&](int tile, float* epi) {
+        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -360,11 +311,41 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
                 *reinterpret_cast<f32x4*>(g.C + size_t(row) * g.ldc + col) = v;
             }
         });
-        __syncthreads();  // epilogue staging is drained before the next tile's K-step 1 is written over it
-        X3_TSTAMP(13);
-#ifdef X3_STAMPS
-        ++tcount;
-#endif
+        __syncthreads();  // epilogue staging is drained before the stage is written again
+    };
+
+    // prologue: item 0 -> LDS stage 0; items 1, 2 in flight in r1, r0
+    load_next(r0);
+    write_stage(0, r0);
+    load_next(r1);
+    load_next(r0);
+    __syncthreads();
+    zero_acc();
+    int tile = first, kt = 0;
+    // one stream item; `nx` holds item s+1 (to be published), then is refilled with item s+3
+    // Order inside an item: the fragment reads of this item are issued FIRST, their LDS latency runs
+    // under the ds_writes / buffer loads of the staging work; the second half's fragments are read
+    // while the first half's 12 MFMAs execute (the two waves of a SIMD run in lockstep, so an LDS
+    // wait of one is not covered by MFMAs of the other).
+    auto item = [&](int s, u32x4 (&nx)[8]) {
+        Frags f0, f1;
+        read_frags(s & 1, 0, f0);
+        write_stage((s + 1) & 1, nx);
+        load_next(nx);
+        read_frags(s & 1, 1, f1);
+        mfma_frags(f0);
+        mfma_frags(f1);
+        __syncthreads();  // stage (s+1)&1 is published, stage s&1 is free
+        if (++kt == nk) {
+            epilogue(tile, reinterpret_cast<float*>(lds + (s & 1) * STAGE));
+            zero_acc();
+            kt = 0;
+            tile += stride;
+        }
+    };
+    for (int s = 0; tile < n_tiles; s += 2) {
+        item(s, r1);
+        if (tile < n_tiles) item(s + 1, r0);
     }
 }
 
