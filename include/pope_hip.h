@@ -103,7 +103,7 @@ typedef struct pope_vit_block_weights {   /* state-dict keys blocks.{i}.*  (devi
     const float *ls2;
     /* optional (POPE_PREC_F16X3): weight planes [out][in] (layout above), scale POPE_PLANES_W_SCALE;
      * NULL -> the layer splits its fp32 weights on the fly */
-    const void *qkv_wp, *fc1_wp, *fc2_wp;
+    const void *qkv_wp, *fc1_wp, *fc2_wp, *proj_wp;
 } pope_vit_block_weights;
 
 typedef struct pope_vit_weights {

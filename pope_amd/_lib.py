@@ -18,7 +18,7 @@ c_ll_p = C.POINTER(C.c_longlong)
 class VitBlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
-        "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "qkv_wp", "fc1_wp", "fc2_wp")]
+        "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "qkv_wp", "fc1_wp", "fc2_wp", "proj_wp")]
 
 
 class VitWeights(C.Structure):

@@ -47,6 +47,9 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
     return d;
 }
 
+// OUT_PLANES: write the output as f16 hi/lo activation planes (pope_hip.h layout, scale 8) for the
+// f16x3 proj GEMM instead of fp32.
+template <bool OUT_PLANES>
 __global__ __launch_bounds__(NT, 2) void attn_f16x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                              int N, int heads) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -246,13 +249,27 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_kernel(const float* __restri
         const int lr = (lane >> 4) + 4 * i, c4 = (lane & 15) * 4;
         const int qrow = q0 + wave * 32 + lr;
         const f32x4 v = *reinterpret_cast<const f32x4*>(&Os[lr * OST + c4]);
-        if (qrow < N) *reinterpret_cast<f32x4*>(out + (size_t(b) * N + qrow) * D + head * HD + c4) = v;
+        if (qrow < N) {
+            if constexpr (OUT_PLANES) {
+                f16x4 hi, lo;
+                split4(v * 8.0f, hi, lo);  // K_PLANES_ACT_SCALE
+                const int col = head * HD + c4;
+                _Float16* o = reinterpret_cast<_Float16*>(out) + (size_t(b) * N + qrow) * 2 * D + (col >> 5) * 64 + (col & 31);
+                *reinterpret_cast<f16x4*>(o) = hi;
+                *reinterpret_cast<f16x4*>(o + 32) = lo;
+            } else {
+                *reinterpret_cast<f32x4*>(out + (size_t(b) * N + qrow) * D + head * HD + c4) = v;
+            }
+        }
     }
 }
 
 }  // namespace
 
-int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream) {
+static_assert(K_PLANES_ACT_SCALE == 8.0f, "attention planes epilogue scale");
+
+template <bool OUT_PLANES>
+static int launch_attn_x3(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream) {
     if (B <= 0 || N <= 0 || heads <= 0 || size_t(B) * heads * ((N + QB - 1) / QB) > 0x7fffffffull) return POPE_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return POPE_ERR_ARG;
     if (size_t(N) * 3 * heads * HD * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
@@ -260,11 +277,19 @@ int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int 
     constexpr size_t lds = X3_ATTN_STAGE_BYTES > X3_ATTN_EPI_BYTES ? X3_ATTN_STAGE_BYTES : X3_ATTN_EPI_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                int(lds)) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_kernel<OUT_PLANES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
             return POPE_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_f16x3_kernel, grid, dim3(NT), lds, stream, qkv, out, N, heads);
+    hipLaunchKernelGGL(attn_f16x3_kernel<OUT_PLANES>, grid, dim3(NT), lds, stream, qkv, out, N, heads);
     return pope_check_launch();
+}
+
+int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream) {
+    return launch_attn_x3<false>(qkv, out, B, N, heads, stream);
+}
+int pope_launch_attention_f16x3_planes(const float* qkv, void* out_planes, int B, int N, int heads, hipStream_t stream) {
+    if ((heads * HD) & 31) return POPE_ERR_ARG;
+    return launch_attn_x3<true>(qkv, static_cast<float*>(out_planes), B, N, heads, stream);
 }

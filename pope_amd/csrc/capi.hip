@@ -183,6 +183,7 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
         const pope_vit_block_weights& k = w->blocks_host[i];
         // x = x + ls1(attn(norm1(x)))                                      block.py:105
         const bool planes = prec == POPE_PREC_F16X3 && k.qkv_wp && k.fc1_wp && k.fc2_wp && dim % 32 == 0 && dim >= 64;
+        const bool proj_planes = planes && k.proj_wp;
         void* xn_pl = xn;    // planes alias the xn / fc1 buffers: 2 x f16 per element = the fp32 footprint
         void* hid_pl = hid;
         POPE_MARK(POPE_K_LAYERNORM);
@@ -199,9 +200,17 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
             if ((rc = pope_linear_prec_f32(xn, k.qkv_w, k.qkv_b, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, prec, stream))) return rc;
         }
         POPE_MARK(POPE_K_ATTENTION);
-        if ((rc = pope_attention_prec_f32(qkv, att, B, ntok, w->heads, prec, stream))) return rc;
+        if (proj_planes) {
+            if ((rc = pope_launch_attention_f16x3_planes(qkv, att, B, ntok, w->heads, stream))) return rc;
+        } else {
+            if ((rc = pope_attention_prec_f32(qkv, att, B, ntok, w->heads, prec, stream))) return rc;
+        }
         POPE_MARK(POPE_K_GEMM_PROJ);
-        if ((rc = pope_linear_prec_f32(att, k.proj_w, k.proj_b, x, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, prec, stream))) return rc;
+        if (proj_planes) {
+            if ((rc = pope_linear_planes_f32(att, k.proj_wp, k.proj_b, x, nullptr, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, stream))) return rc;
+        } else {
+            if ((rc = pope_linear_prec_f32(att, k.proj_w, k.proj_b, x, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, prec, stream))) return rc;
+        }
         // x = x + ls2(mlp(norm2(x)))                                       block.py:106
         POPE_MARK(POPE_K_LAYERNORM);
         if (planes) {

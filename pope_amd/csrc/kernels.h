@@ -57,6 +57,8 @@ int pope_launch_layernorm_f32(const float* x, int ldx, const float* w, const flo
 // Multi-head softmax attention over qkv[B, N, 3, heads, 64] -> out[B, N, heads*64].
 int pope_launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream);
 int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream);
+// same, output as activation planes [B*N, heads*64] for the f16x3 proj GEMM
+int pope_launch_attention_f16x3_planes(const float* qkv, void* out_planes, int B, int N, int heads, hipStream_t stream);
 
 struct MatchParams {
     const float* feat0;  // [n, L, C]

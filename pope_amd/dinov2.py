@@ -161,7 +161,8 @@ class DinoVisionTransformer(nn.Module):
                 P(b.norm1.weight), P(b.norm1.bias), P(b.attn.qkv.weight), P(b.attn.qkv.bias),
                 P(b.attn.proj.weight), P(b.attn.proj.bias), P(b.ls1.gamma), P(b.norm2.weight), P(b.norm2.bias),
                 P(b.mlp.fc1.weight), P(b.mlp.fc1.bias), P(b.mlp.fc2.weight), P(b.mlp.fc2.bias), P(b.ls2.gamma),
-                planes(b.attn.qkv.weight), planes(b.mlp.fc1.weight), planes(b.mlp.fc2.weight))
+                planes(b.attn.qkv.weight), planes(b.mlp.fc1.weight), planes(b.mlp.fc2.weight),
+                planes(b.attn.proj.weight))
         w = _lib.VitWeights(self.embed_dim, self.n_blocks, self.num_heads, self.patch_size,
                             self.blocks[0].mlp.fc1.weight.shape[0],
                             P(self.patch_embed.proj.weight.reshape(self.embed_dim, -1)),
