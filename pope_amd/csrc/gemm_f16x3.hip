@@ -228,12 +228,19 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     if (first >= n_tiles) return;
     int ld_tile = first, ld_kt = 0;  // next stream item to load
     auto load_next = [&](u32x4 (&st)[8]) {
-        if (ld_tile < n_tiles) {
-            const int m0 = (ld_tile / tiles_n) * BM, n0 = (ld_tile % tiles_n) * BN;
+        {   // branch-free (an item must be ONE basic block for the interleave below): past the end of the
+            // stream the last tile is re-loaded and never consumed
+            const int lt = ld_tile < n_tiles ? ld_tile : n_tiles - 1;
+            const int m0 = (lt / tiles_n) * BM, n0 = (lt % tiles_n) * BN;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+#ifdef X3_L1ONLY  // timing experiment: every load hits the same few lines (no L2 traffic; wrong results)
+                const unsigned va = unsigned((prow + 32 * i) & 7) * unsigned(g.lda) * 4u + pc * 16u + 0 * m0;
+                const unsigned vw = unsigned((prow + 32 * i) & 7) * unsigned(g.ldw) * 4u + pc * 16u + 0 * n0;
+#else
                 const unsigned va = unsigned(m0 + prow + 32 * i) * unsigned(g.lda) * 4u + pc * 16u;
                 const unsigned vw = unsigned(n0 + prow + 32 * i) * unsigned(g.ldw) * 4u + pc * 16u;
+#endif
                 st[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, ld_kt * 128, 0);
                 st[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, ld_kt * 128, 0);
             }
@@ -305,10 +312,18 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
                 f16x4 hi, lo;
                 split(v, A_SCALE, hi, lo);
                 _Float16* o = static_cast<_Float16*>(g.c_pl) + size_t(row) * 2 * g.ldc + (col >> 5) * 64 + (col & 31);
-                *reinterpret_cast<f16x4*>(o) = hi;
-                *reinterpret_cast<f16x4*>(o + 32) = lo;
+                __builtin_nontemporal_store(hi, reinterpret_cast<f16x4*>(o));
+                __builtin_nontemporal_store(lo, reinterpret_cast<f16x4*>(o + 32));
             } else {
-                *reinterpret_cast<f32x4*>(g.C + size_t(row) * g.ldc + col) = v;
+#if defined(X3_NOSTORE)
+                if (v[0] == 1234.5678f) *reinterpret_cast<f32x4*>(g.C + size_t(row) * g.ldc + col) = v;
+#else
+                // write-once outputs (qkv: 450 MB per launch, far beyond L2) are stored non-temporally so they
+                // do not displace the A/W panels in L2 (+5 %); the residual stream (LS_RES) is re-read by
+                // the next LayerNorm and keeps the default policy
+                if constexpr (EPI == EPI_BIAS_LS_RES) *reinterpret_cast<f32x4*>(g.C + size_t(row) * g.ldc + col) = v;
+                else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g.C + size_t(row) * g.ldc + col));
+#endif
             }
         });
         __syncthreads();  // epilogue staging is drained before the stage is written again
@@ -335,6 +350,20 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
         read_frags(s & 1, 1, f1);
         mfma_frags(f0);
         mfma_frags(f1);
+#ifndef X3_NO_SCHED
+        // Pin the instruction mix (LLVM sched groups 0x8 MFMA, 0x100 DS read, 0x200 DS write, 0x20 VMEM
+        // read): the LDS writes, buffer loads and second-half fragment reads are spread between the 24
+        // MFMAs instead of forming their own phases — all waves of a CU run in lockstep, so a phase that
+        // uses only the LDS or only the load path leaves the matrix pipe idle on the whole CU.
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // f0
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (i >= 2 && i < 10) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // f1
+            if (i >= 8 && i < 16) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#endif
         __syncthreads();  // stage (s+1)&1 is published, stage s&1 is free
         if (++kt == nk) {
             epilogue(tile, reinterpret_cast<float*>(lds + (s & 1) * STAGE));
