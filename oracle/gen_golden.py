@@ -54,6 +54,108 @@ def load_reference_coarse_matching():
     return mod.CoarseMatching(cfg).eval()
 
 
+def load_reference_matcher(cfg_overrides=None):
+    """Reference `Matcher` (src/matcher/matcher.py) with in-memory stand-ins for the two third-party modules
+    absent from this image: `yacs.config.CfgNode` (a dict with attribute access) and the two
+    kornia functions fine_matching.py:5-6 imports, restated from their published closed forms."""
+    import types
+
+    class CfgNode(dict):
+        __getattr__ = dict.__getitem__
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+    def create_meshgrid(h, w, normalized_coordinates=True, device=None):
+        xs = torch.linspace(-1, 1, w, device=device) if normalized_coordinates else torch.arange(w, device=device).float()
+        ys = torch.linspace(-1, 1, h, device=device) if normalized_coordinates else torch.arange(h, device=device).float()
+        gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+        return torch.stack([gx, gy], -1)[None]
+
+    def spatial_expectation2d(heatmap, normalized_coordinates=True):
+        b, c, h, w = heatmap.shape
+        grid = create_meshgrid(h, w, normalized_coordinates, heatmap.device).reshape(-1, 2)
+        return (heatmap.reshape(b, c, -1, 1) * grid).sum(2)
+
+    def module(name, **attrs):
+        m = sys.modules.setdefault(name, types.ModuleType(name))
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+
+    module("yacs", config=module("yacs.config", CfgNode=CfgNode))
+    dsnt = module("kornia.geometry.subpix.dsnt", spatial_expectation2d=spatial_expectation2d)
+    module("kornia"), module("kornia.geometry"), module("kornia.geometry.subpix", dsnt=dsnt)
+    module("kornia.utils"), module("kornia.utils.grid", create_meshgrid=create_meshgrid)
+    import copy
+    from src.matcher import Matcher, default_cfg
+    cfg = copy.deepcopy(default_cfg)
+    for k, v in (cfg_overrides or {}).items():
+        cfg["match_coarse"][k] = v
+    return Matcher(cfg).eval(), cfg
+
+
+def gen_loftr():
+    """tests/golden/loftr_*.npz: the reference Matcher on seeded synthetic weights (synth.synthetic_matcher_state_dict)
+    and gray pairs; checks oracle/loftr_ref.py stage by stage first."""
+    from oracle import loftr_ref
+    from pope_amd.matcher import default_cfg as my_cfg
+    sd = synth.synthetic_matcher_state_dict(seed=0)
+    digest = sd_digest({k: v for k, v in sd.items() if v.dtype.is_floating_point})
+    cases = {
+        # name: (n, (h0,w0), (h1,w1), thr)
+        "loftr_256": (2, (256, 256), (256, 256), 0.2),          # the drivers' shape (eval_linemod_json.py:103-111)
+        "loftr_256_lowthr": (2, (256, 256), (256, 256), 1e-3),   # thr lowered so the fine stage sees matches
+        "loftr_192x256_vs_256x192": (1, (192, 256), (256, 192), 1e-3),
+    }
+    for name, (n, s0, s1, thr) in cases.items():
+        i0, i1 = synth.synthetic_gray_pairs(n, *s0, seed=21)
+        if s1 != s0:   # different shapes: image1 = fresh texture with a 192x192 region of image0 pasted 32 rows lower
+            i1 = synth.synthetic_gray_pairs(n, *s1, seed=22)[0]
+            i1[:, :, 32:224, :] = i0[:, :, :, 32:224]
+        ref, cfg = load_reference_matcher({"thr": thr})
+        ref.load_state_dict({"matcher." + k: v.clone() for k, v in sd.items()}, strict=True)  # prefix path, matcher.py:81-85
+        data = {"image0": i0, "image1": i1}
+        with torch.no_grad():
+            ref(data)
+            fc0, fc1 = ref({"image0": i0, "image1": i1}, only_att_fea=True)
+            if s0 == s1:
+                bc, bf = ref.backbone(torch.cat([i0, i1], 0))
+            else:
+                bc, bf = ref.backbone(i0)
+        cfg2 = dict(my_cfg, match_coarse=dict(my_cfg["match_coarse"], thr=thr))
+        assert {k: v for k, v in cfg.items() if k != "match_coarse"} == {k: v for k, v in my_cfg.items() if k != "match_coarse"}
+        with torch.no_grad():
+            mine = loftr_ref.matcher_forward(sd, cfg2, i0, i1)
+            mbc, mbf = loftr_ref.resnet_fpn_8_2(sd, torch.cat([i0, i1], 0) if s0 == s1 else i0)
+        d = {"backbone_c": maxdiff(bc, mbc), "backbone_f": maxdiff(bf, mbf),
+             "feat_c0": maxdiff(fc0, mine["feat_c0"]), "feat_c1": maxdiff(fc1, mine["feat_c1"]),
+             "conf": maxdiff(data["conf_matrix"], mine["conf_matrix"])}
+        for k in ("b_ids", "i_ids", "j_ids"):
+            assert torch.equal(data[k], mine[k]), k
+        for k in ("mconf", "mkpts0_c", "mkpts1_c", "mkpts0_f", "mkpts1_f", "expec_f"):
+            d[k] = maxdiff(data[k], mine[k]) if data[k].numel() else 0.0
+        print(name, "thr", thr, "matches", len(data["b_ids"]), "oracle-vs-reference:", {k: f"{v:.1e}" for k, v in d.items()})
+        assert max(d.values()) <= 1e-5, d
+        assert tuple(data["hw0_c"]) == mine["hw0_c"] and tuple(data["hw0_f"]) == mine["hw0_f"] and data["W"] == 5
+        conf = data["conf_matrix"]
+        full = {} if name == "loftr_256" else {   # complete coarse features of pair 0: input of the strict
+            "feat_c0_b0": fc0[0].numpy(), "feat_c1_b0": fc1[0].numpy()}   # index-parity test of the HIP matcher
+        np.savez(os.path.join(OUT, name + ".npz"), **full,
+                 weights_seed=0, weights_digest=digest, thr=np.float64(thr), n=n, shape0=np.array(s0), shape1=np.array(s1),
+                 image_digest=np.array([float(i0.double().sum()), float(i1.double().sum())]),
+                 backbone_c=bc[:1, :, ::2, ::2].numpy(), backbone_f=bf[:1, ::4, ::8, ::8].numpy(),
+                 feat_c0=fc0[:, ::8].numpy(), feat_c1=fc1[:, ::8].numpy(),
+                 conf_rowmax=conf.max(2)[0].numpy(), conf_rowarg=conf.max(2)[1].numpy(),
+                 conf_colmax=conf.max(1)[0].numpy(), conf_colarg=conf.max(1)[1].numpy(),
+                 conf_sum=np.array([float(conf.double().sum())]),
+                 b_ids=data["b_ids"].numpy(), i_ids=data["i_ids"].numpy(), j_ids=data["j_ids"].numpy(),
+                 mconf=data["mconf"].numpy(), mkpts0_c=data["mkpts0_c"].numpy(), mkpts1_c=data["mkpts1_c"].numpy(),
+                 mkpts0_f=data["mkpts0_f"].numpy(), mkpts1_f=data["mkpts1_f"].numpy(), expec_f=data["expec_f"].numpy(),
+                 hw0_c=np.array(data["hw0_c"]), hw1_c=np.array(data["hw1_c"]), hw0_f=np.array(data["hw0_f"]),
+                 hw1_f=np.array(data["hw1_f"]))
+
+
 def sd_digest(sd):
     return np.array([float(sd[k].double().sum()) for k in sorted(sd)], np.float64)
 
@@ -81,6 +183,8 @@ def run_ref_vit(model, x):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-loftr" in sys.argv:
+        return gen_loftr()
     sd = synth.synthetic_state_dict(seed=0)
     assert len(sd) == 175
     model = load_reference_vit(sd)
@@ -188,6 +292,7 @@ def main():
     assert (s2 == slots).all() and list(t2) == top
     np.savez(os.path.join(OUT, "top3.npz"), ref=ref.numpy(), fea=fea.numpy(), scores=scores.numpy(),
              slot_scores=slots, slot_index=np.array(top))
+    gen_loftr()
     print("golden fixtures written to", OUT)
 
 

@@ -1,0 +1,305 @@
+"""LoFTR stages either side of the HIP coarse matcher ("adjacent: torch/MIOpen
+first"): local-feature CNN, sinusoidal position code, linear-attention transformer, fine window
+preprocessing and sub-pixel refinement.  These are tensor plumbing on PyTorch-ROCm (MIOpen convolutions,
+rocBLAS linears) around `pope_amd.matcher.CoarseMatching`, which is the hand-written part.
+
+Every module keeps the reference's parameter names and shapes so that `weights/matcher.pth` loads with
+strict=True (211 keys: backbone.* 107, loftr_coarse.* 80, fine_preprocess.* 4, loftr_fine.* 20), but the
+computation is organised for inference on one big GPU:
+  * eval-mode BatchNorm is folded into the preceding convolution once per weight load (one pass over the
+    activations instead of two; resnet_fpn.py:27-40,60-63,72-84 keep conv and BN separate);
+  * fine windows are gathered only at the M matched cells instead of unfolding every window of the
+    1/2-resolution map and indexing afterwards (fine_preprocess.py:44-51 materialises [n, L, 25, 128]);
+  * the position code is generated for the requested grid, not sliced from a 256x256 buffer.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------ CNN
+def _fold_bn(conv_w, bn):
+    """Filter and bias of conv -> BatchNorm(eval) as one convolution."""
+    g = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    return conv_w * g.view(-1, 1, 1, 1), bn.bias - bn.running_mean * g
+
+
+class BasicBlock(nn.Module):
+    """resnet_fpn.py:15-40: relu(x' + bn2(conv2(relu(bn1(conv1(x)))))), x' = 1x1 stride-s conv + BN if s != 1."""
+
+    def __init__(self, in_planes, planes, stride=1):
+        super().__init__()
+        self.stride = stride
+        self.conv1 = nn.Conv2d(in_planes, planes, 3, stride, 1, bias=False)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1:
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride, bias=False),
+                                            nn.BatchNorm2d(planes))
+
+    def folded(self):
+        f = [_fold_bn(self.conv1.weight, self.bn1), _fold_bn(self.conv2.weight, self.bn2)]
+        if self.downsample is not None:
+            f.append(_fold_bn(self.downsample[0].weight, self.downsample[1]))
+        return f
+
+    def run(self, x, f):
+        y = F.relu_(F.conv2d(x, f[0][0], f[0][1], self.stride, 1))
+        y = F.conv2d(y, f[1][0], f[1][1], 1, 1)
+        if self.downsample is not None:
+            x = F.conv2d(x, f[2][0], f[2][1], self.stride)
+        return F.relu_(y.add_(x))
+
+
+class ResNetFPN_8_2(nn.Module):
+    """resnet_fpn.py:43-118.  [B,1,H,W] -> coarse [B,256,H/8,W/8], fine [B,128,H/2,W/2]."""
+
+    def __init__(self, config):
+        super().__init__()
+        d0 = config["initial_dim"]
+        d1, d2, d3 = config["block_dims"]
+        self.conv1 = nn.Conv2d(1, d0, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(d0)
+        self.layer1 = nn.Sequential(BasicBlock(d0, d1, 1), BasicBlock(d1, d1, 1))
+        self.layer2 = nn.Sequential(BasicBlock(d1, d2, 2), BasicBlock(d2, d2, 1))
+        self.layer3 = nn.Sequential(BasicBlock(d2, d3, 2), BasicBlock(d3, d3, 1))
+        self.layer3_outconv = nn.Conv2d(d3, d3, 1, bias=False)
+        self.layer2_outconv = nn.Conv2d(d2, d3, 1, bias=False)
+        self.layer2_outconv2 = nn.Sequential(nn.Conv2d(d3, d3, 3, 1, 1, bias=False), nn.BatchNorm2d(d3),
+                                             nn.LeakyReLU(), nn.Conv2d(d3, d2, 3, 1, 1, bias=False))
+        self.layer1_outconv = nn.Conv2d(d1, d2, 1, bias=False)
+        self.layer1_outconv2 = nn.Sequential(nn.Conv2d(d2, d2, 3, 1, 1, bias=False), nn.BatchNorm2d(d2),
+                                             nn.LeakyReLU(), nn.Conv2d(d2, d1, 3, 1, 1, bias=False))
+        for m in self.modules():  # resnet_fpn.py:87-92
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._folded = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
+
+    def _fold(self):
+        with torch.no_grad():
+            return {
+                "stem": _fold_bn(self.conv1.weight, self.bn1),
+                "blocks": [[b.folded() for b in layer] for layer in (self.layer1, self.layer2, self.layer3)],
+                "out2": _fold_bn(self.layer2_outconv2[0].weight, self.layer2_outconv2[1]),
+                "out1": _fold_bn(self.layer1_outconv2[0].weight, self.layer1_outconv2[1]),
+            }
+
+    def invalidate(self):
+        self._folded = None
+
+    def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float() move the parameters: refold lazily
+        self._folded = None
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("pope_amd: inference only (BatchNorm is folded; call .eval())")
+        if self._folded is None:
+            self._folded = self._fold()
+        f = self._folded
+        x0 = F.relu_(F.conv2d(x, f["stem"][0], f["stem"][1], 2, 3))
+        feats = []
+        h = x0
+        for layer, lf in zip((self.layer1, self.layer2, self.layer3), f["blocks"]):
+            for blk, bf in zip(layer, lf):
+                h = blk.run(h, bf)
+            feats.append(h)
+        x1, x2, x3 = feats
+        up = lambda t: F.interpolate(t, scale_factor=2.0, mode="bilinear", align_corners=True)  # noqa: E731
+        x3_out = self.layer3_outconv(x3)
+        t = self.layer2_outconv(x2).add_(up(x3_out))
+        t = F.leaky_relu_(F.conv2d(t, f["out2"][0], f["out2"][1], 1, 1))
+        x2_out = self.layer2_outconv2[3](t)
+        t = self.layer1_outconv(x1).add_(up(x2_out))
+        t = F.leaky_relu_(F.conv2d(t, f["out1"][0], f["out1"][1], 1, 1))
+        x1_out = self.layer1_outconv2[3](t)
+        return [x3_out, x1_out]
+
+
+def build_backbone(config):
+    """backbone/__init__.py:4-11; only the (8, 2) resolution is used by cvpr_ds_config.py:9."""
+    if config["backbone_type"] != "ResNetFPN" or tuple(config["resolution"]) != (8, 2):
+        raise ValueError(f"pope_amd: unsupported LoFTR backbone {config['backbone_type']} {config['resolution']}")
+    return ResNetFPN_8_2(config["resnetfpn"])
+
+
+# ------------------------------------------------------------------------------------ position code
+class PositionEncodingSine(nn.Module):
+    """utils/position_encoding.py:11-42.  Channel 4k..4k+3 = sin(x w_k), cos(x w_k), sin(y w_k), cos(y w_k)
+    with x, y counted from 1.  temp_bug_fix=False (cvpr_ds_config.py:28) selects the released models'
+    frequencies: the reference's expression `-log(1e4) / d_model // 2` floors to -1, i.e. w_k = exp(-2k)
+    (:28); temp_bug_fix=True gives w_k = 1e4^(-2k / (d_model/2)) (:26)."""
+
+    def __init__(self, d_model, max_shape=(256, 256), temp_bug_fix=True):
+        super().__init__()
+        self.d_model, self.max_shape, self.temp_bug_fix = d_model, tuple(max_shape), temp_bug_fix
+        self._cache = {}
+
+    def code(self, h, w, device):
+        key = (h, w, str(device))
+        if key not in self._cache:
+            if h > self.max_shape[0] or w > self.max_shape[1]:
+                raise ValueError(f"feature map {h}x{w} exceeds max_shape {self.max_shape}")
+            k = torch.arange(0, self.d_model // 2, 2).float()
+            rate = -math.log(10000.0) / (self.d_model // 2) if self.temp_bug_fix else float(
+                -math.log(10000.0) / self.d_model // 2)
+            freq = torch.exp(k * rate)[:, None, None]
+            xs = torch.arange(1, w + 1).float().view(1, 1, w).expand(1, h, w)
+            ys = torch.arange(1, h + 1).float().view(1, h, 1).expand(1, h, w)
+            pe = torch.stack([torch.sin(xs * freq), torch.cos(xs * freq), torch.sin(ys * freq),
+                              torch.cos(ys * freq)], 1)                      # [d/4, 4, h, w]
+            self._cache[key] = pe.reshape(1, self.d_model, h, w).to(device)
+        return self._cache[key]
+
+    def forward(self, x):
+        return x + self.code(x.shape[2], x.shape[3], x.device)
+
+
+# -------------------------------------------------------------------------------- linear attention
+def linear_attention(q, k, v, eps=1e-6):
+    """loftr_module/linear_attention.py:20-47 (no masks): phi = elu + 1;
+    out_l = phi(q_l) (sum_s phi(k_s) v_s^T) / (phi(q_l) . sum_s phi(k_s) + eps).
+    q [n,L,h,d], k,v [n,S,h,d].  The reference divides v by S and multiplies back afterwards; kept, since
+    it changes the rounding."""
+    S = v.shape[1]
+    Q, K = F.elu(q) + 1, F.elu(k) + 1
+    kv = torch.einsum("nshd,nshv->nhdv", K, v / S)
+    z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(1)) + eps)
+    return torch.einsum("nlhd,nhdv,nlh->nlhv", Q, kv, z) * S
+
+
+class LoFTREncoderLayer(nn.Module):
+    """loftr_module/transformer.py:7-58."""
+
+    def __init__(self, d_model, nhead, attention="linear"):
+        super().__init__()
+        if attention != "linear":
+            raise NotImplementedError("pope_amd: only linear attention (cvpr_ds_config.py:27,49)")
+        self.dim, self.nhead = d_model // nhead, nhead
+        self.q_proj = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.merge = nn.Linear(d_model, d_model, bias=False)
+        self.mlp = nn.Sequential(nn.Linear(2 * d_model, 2 * d_model, bias=False), nn.ReLU(True),
+                                 nn.Linear(2 * d_model, d_model, bias=False))
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, x, source, x_mask=None, source_mask=None):
+        if x_mask is not None or source_mask is not None:
+            raise NotImplementedError("pope_amd: padding masks are a training-time path (matcher.py:62-64)")
+        n = x.shape[0]
+        q = self.q_proj(x).view(n, -1, self.nhead, self.dim)
+        k = self.k_proj(source).view(n, -1, self.nhead, self.dim)
+        v = self.v_proj(source).view(n, -1, self.nhead, self.dim)
+        msg = self.norm1(self.merge(linear_attention(q, k, v).reshape(n, -1, self.nhead * self.dim)))
+        return x + self.norm2(self.mlp(torch.cat([x, msg], 2)))
+
+
+class LocalFeatureTransformer(nn.Module):
+    """loftr_module/transformer.py:61-106; 'cross' layers update feat0 first and feed the NEW feat0 into
+    the feat1 update (:101-102)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.d_model, self.nhead, self.layer_names = config["d_model"], config["nhead"], config["layer_names"]
+        self.layers = nn.ModuleList([LoFTREncoderLayer(self.d_model, self.nhead, config["attention"])
+                                     for _ in self.layer_names])
+        for p in self.parameters():  # transformer.py:77-80
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, feat0, feat1, mask0=None, mask1=None):
+        assert self.d_model == feat0.size(2), "the feature number of src and transformer must be equal"
+        for layer, name in zip(self.layers, self.layer_names):
+            if name == "self":
+                feat0 = layer(feat0, feat0, mask0, mask0)
+                feat1 = layer(feat1, feat1, mask1, mask1)
+            elif name == "cross":
+                feat0 = layer(feat0, feat1, mask0, mask1)
+                feat1 = layer(feat1, feat0, mask1, mask0)
+            else:
+                raise KeyError(name)
+        return feat0, feat1
+
+
+# ------------------------------------------------------------------------------------- fine stage
+def gather_windows(feat_f, b_ids, cell_ids, w_c, W, stride):
+    """Rows `feat_unfold[b, cell]` of the reference's unfold (fine_preprocess.py:44-51) without building
+    the unfold: window (W x W, zero padded by W//2) of feat_f [n,C,Hf,Wf] centred on fine pixel
+    (cy*stride, cx*stride) for coarse cell id = cy*w_c + cx.  Returns [M, W*W, C], window index kh*W+kw."""
+    pad = W // 2
+    fp = F.pad(feat_f, (pad, pad, pad, pad))
+    d = torch.arange(W, device=feat_f.device)
+    ys = ((cell_ids // w_c) * stride)[:, None, None] + d[None, :, None]   # [M, W, 1] (already offset by pad)
+    xs = ((cell_ids % w_c) * stride)[:, None, None] + d[None, None, :]    # [M, 1, W]
+    win = fp[b_ids[:, None, None], :, ys, xs]                             # [M, W, W, C]
+    return win.reshape(win.shape[0], W * W, -1)
+
+
+class FinePreprocess(nn.Module):
+    """loftr_module/fine_preprocess.py:7-59."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.cat_c_feat = config["fine_concat_coarse_feat"]
+        self.W = config["fine_window_size"]
+        d_c, d_f = config["coarse"]["d_model"], config["fine"]["d_model"]
+        self.d_model_f = d_f
+        if self.cat_c_feat:
+            self.down_proj = nn.Linear(d_c, d_f, bias=True)
+            self.merge_feat = nn.Linear(2 * d_f, d_f, bias=True)
+        for p in self.parameters():  # fine_preprocess.py:24-27
+            if p.dim() > 1:
+                nn.init.kaiming_normal_(p, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, feat_f0, feat_f1, feat_c0, feat_c1, data):
+        W = self.W
+        stride = data["hw0_f"][0] // data["hw0_c"][0]
+        data.update({"W": W})
+        b, i, j = data["b_ids"], data["i_ids"], data["j_ids"]
+        if b.shape[0] == 0:
+            empty = torch.empty(0, W * W, self.d_model_f, device=feat_f0.device)
+            return empty, empty.clone()
+        # NB the reference unfolds image 1 with image 0's stride and both with their own width (:44-47)
+        win0 = gather_windows(feat_f0, b, i, data["hw0_c"][1], W, stride)
+        win1 = gather_windows(feat_f1, b, j, data["hw1_c"][1], W, stride)
+        if self.cat_c_feat:
+            c_win = self.down_proj(torch.cat([feat_c0[b, i], feat_c1[b, j]], 0))               # [2M, d_f]
+            both = torch.cat([torch.cat([win0, win1], 0), c_win[:, None, :].expand(-1, W * W, -1)], -1)
+            win0, win1 = torch.chunk(self.merge_feat(both), 2, dim=0)
+        return win0, win1
+
+
+class FineMatching(nn.Module):
+    """utils/fine_matching.py:9-74: correlate the centre of window 0 with window 1, softmax(1/sqrt(C)),
+    expectation over the normalised [-1,1]^2 grid (x,y) (kornia dsnt.spatial_expectation2d / create_meshgrid
+    in the reference; both are closed-form and restated here, see SURVEY.md §8c 'unpinned')."""
+
+    def forward(self, feat_f0, feat_f1, data):
+        M, WW, C = feat_f0.shape
+        W = int(math.sqrt(WW))
+        scale = data["hw0_i"][0] / data["hw0_f"][0]
+        if M == 0:
+            data.update({"expec_f": torch.empty(0, 3, device=feat_f0.device),
+                         "mkpts0_f": data["mkpts0_c"], "mkpts1_f": data["mkpts1_c"]})
+            return
+        sim = torch.einsum("mc,mrc->mr", feat_f0[:, WW // 2, :], feat_f1)
+        heat = torch.softmax(sim * (1.0 / C ** 0.5), dim=1)                          # [M, WW]
+        lin = torch.linspace(-1, 1, W, device=heat.device)
+        grid = torch.stack(torch.meshgrid(lin, lin, indexing="ij")[::-1], -1).reshape(1, WW, 2)  # (x, y)
+        coords = (heat[:, :, None] * grid).sum(1)                                     # [M, 2]
+        var = (grid ** 2 * heat[:, :, None]).sum(1) - coords ** 2
+        std = torch.sqrt(torch.clamp(var, min=1e-10)).sum(-1)
+        data.update({"expec_f": torch.cat([coords, std[:, None]], -1)})
+        # get_fine_match (:61-74): image 0 keeps its coarse cell centre, image 1 moves inside the window
+        scale1 = scale * data["scale1"][data["b_ids"]] if "scale0" in data else scale
+        data.update({"mkpts0_f": data["mkpts0_c"],
+                     "mkpts1_f": data["mkpts1_c"] + (coords * (W // 2) * scale1)[:len(data["mconf"])]})

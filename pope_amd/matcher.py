@@ -109,3 +109,54 @@ class CoarseMatching(nn.Module):
                           self.temperature)
         out.pop("counts")
         data.update(out)
+
+
+class Matcher(nn.Module):
+    """Drop-in for the reference `Matcher` (src/matcher/matcher.py:12-85): same constructor, same in-place
+    `forward(data, only_att_fea=False)` protocol and published keys, same checkpoint layout (`matcher.`
+    prefix stripped on load, :81-85).  The coarse matching stage runs on the HIP kernels; the CNN and the
+    linear-attention transformers are PyTorch-ROCm plumbing (pope_amd/loftr.py)."""
+
+    def __init__(self, config):
+        super().__init__()
+        from . import loftr
+        self.config = config
+        self.backbone = loftr.build_backbone(config)
+        self.pos_encoding = loftr.PositionEncodingSine(config["coarse"]["d_model"],
+                                                       temp_bug_fix=config["coarse"]["temp_bug_fix"])
+        self.loftr_coarse = loftr.LocalFeatureTransformer(config["coarse"])
+        self.coarse_matching = CoarseMatching(config["match_coarse"])
+        self.fine_preprocess = loftr.FinePreprocess(config)
+        self.loftr_fine = loftr.LocalFeatureTransformer(config["fine"])
+        self.fine_matching = loftr.FineMatching()
+
+    @torch.no_grad()
+    def forward(self, data, only_att_fea=False):
+        im0, im1 = data["image0"], data["image1"]
+        require_cuda(im0, "Matcher")
+        require_cuda(im1, "Matcher")
+        if "mask0" in data:
+            raise NotImplementedError("pope_amd: padding masks are a training-time path (matcher.py:62-64)")
+        n = im0.size(0)
+        data.update({"bs": n, "hw0_i": im0.shape[2:], "hw1_i": im1.shape[2:]})
+        if data["hw0_i"] == data["hw1_i"]:  # one CNN launch sequence for both images (matcher.py:46-48)
+            feats_c, feats_f = self.backbone(torch.cat([im0, im1], 0))
+            (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(n), feats_f.split(n)
+        else:
+            (feat_c0, feat_f0), (feat_c1, feat_f1) = self.backbone(im0), self.backbone(im1)
+        data.update({"hw0_c": feat_c0.shape[2:], "hw1_c": feat_c1.shape[2:],
+                     "hw0_f": feat_f0.shape[2:], "hw1_f": feat_f1.shape[2:]})
+        feat_c0 = self.pos_encoding(feat_c0).flatten(2).transpose(1, 2)   # 'n c h w -> n (h w) c'
+        feat_c1 = self.pos_encoding(feat_c1).flatten(2).transpose(1, 2)
+        feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1)
+        if only_att_fea:
+            return feat_c0, feat_c1
+        self.coarse_matching(feat_c0, feat_c1, data)
+        win0, win1 = self.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data)
+        if win0.size(0) != 0:
+            win0, win1 = self.loftr_fine(win0, win1)
+        self.fine_matching(win0, win1, data)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        state_dict = {(k[len("matcher."):] if k.startswith("matcher.") else k): v for k, v in state_dict.items()}
+        return super().load_state_dict(state_dict, *args, **kwargs)

@@ -75,3 +75,94 @@ def synthetic_pairs(n_pairs, h=476, w=630, seed=0, shift=(14, 28), noise=0.1, de
     if noise > 0:
         img1 = img1 + noise * torch.randn(img1.shape, generator=g, dtype=torch.float32)
     return img0.to(device), img1.contiguous().to(device)
+
+
+def synthetic_matcher_state_dict(seed=0, cfg=None):
+    """Seeded synthetic LoFTR `Matcher` weights in the reference checkpoint layout (211 keys,
+    src/matcher/matcher.py:18-27; weights/matcher.pth is not available offline).  Fan-in scaled normal
+    filters; BatchNorm statistics and affines are randomised (the reference's fresh-module defaults are
+    the identity, which would not exercise BN folding)."""
+    if cfg is None:
+        from .matcher import default_cfg as cfg
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, std=1.0):
+        return torch.randn(*shape, generator=g, dtype=torch.float32) * std
+
+    def ru(*shape, lo=0.5, hi=1.5):
+        return lo + (hi - lo) * torch.rand(*shape, generator=g, dtype=torch.float32)
+
+    sd = {}
+
+    def conv(name, cout, cin, k, gain=1.0):
+        sd[name + ".weight"] = rn(cout, cin, k, k, std=math.sqrt(gain / (cin * k * k)))
+
+    def bn(name, c):
+        sd[name + ".weight"] = ru(c)
+        sd[name + ".bias"] = rn(c, std=0.1)
+        sd[name + ".running_mean"] = rn(c, std=0.1)
+        sd[name + ".running_var"] = ru(c)
+        sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    d0 = cfg["resnetfpn"]["initial_dim"]
+    d1, d2, d3 = cfg["resnetfpn"]["block_dims"]
+    conv("backbone.conv1", d0, 1, 7, gain=8.0)
+    bn("backbone.bn1", d0)
+    cin = d0
+    for li, (dim, stride) in enumerate(((d1, 1), (d2, 2), (d3, 2)), start=1):
+        for bi in range(2):
+            p = f"backbone.layer{li}.{bi}"
+            conv(p + ".conv1", dim, cin if bi == 0 else dim, 3)
+            conv(p + ".conv2", dim, dim, 3)
+            bn(p + ".bn1", dim)
+            bn(p + ".bn2", dim)
+            if bi == 0 and stride != 1:
+                conv(p + ".downsample.0", dim, cin, 1)
+                bn(p + ".downsample.1", dim)
+        cin = dim
+    conv("backbone.layer3_outconv", d3, d3, 1, gain=2.0)
+    conv("backbone.layer2_outconv", d3, d2, 1)
+    conv("backbone.layer2_outconv2.0", d3, d3, 3)
+    bn("backbone.layer2_outconv2.1", d3)
+    conv("backbone.layer2_outconv2.3", d2, d3, 3)
+    conv("backbone.layer1_outconv", d2, d1, 1)
+    conv("backbone.layer1_outconv2.0", d2, d2, 3)
+    bn("backbone.layer1_outconv2.1", d2)
+    conv("backbone.layer1_outconv2.3", d1, d2, 3)
+
+    def transformer(prefix, c):
+        # small LayerNorm gains keep the residual stream O(1): with unit gains eight layers of O(1) messages
+        # make <f0,f1>/(C*0.1) so large that the dual softmax saturates to exact 0/1 confidences
+        d, n_layers = c["d_model"], len(c["layer_names"])
+        for i in range(n_layers):
+            p = f"{prefix}.layers.{i}."
+            for nm in ("q_proj", "k_proj", "v_proj", "merge"):
+                sd[p + nm + ".weight"] = rn(d, d, std=1.0 / math.sqrt(d))
+            sd[p + "mlp.0.weight"] = rn(2 * d, 2 * d, std=1.0 / math.sqrt(2 * d))
+            sd[p + "mlp.2.weight"] = rn(d, 2 * d, std=math.sqrt(2.0 / (2 * d)))
+            for nm in ("norm1", "norm2"):
+                sd[p + nm + ".weight"] = ru(d, lo=0.3, hi=0.5)
+                sd[p + nm + ".bias"] = rn(d, std=0.02)
+
+    transformer("loftr_coarse", cfg["coarse"])
+    dc, df = cfg["coarse"]["d_model"], cfg["fine"]["d_model"]
+    sd["fine_preprocess.down_proj.weight"] = rn(df, dc, std=1.0 / math.sqrt(dc))
+    sd["fine_preprocess.down_proj.bias"] = rn(df, std=0.05)
+    sd["fine_preprocess.merge_feat.weight"] = rn(df, 2 * df, std=1.0 / math.sqrt(2 * df))
+    sd["fine_preprocess.merge_feat.bias"] = rn(df, std=0.05)
+    transformer("loftr_fine", cfg["fine"])
+    return sd
+
+
+def synthetic_gray_pairs(n_pairs, h=256, w=256, seed=0, shift=(8, 16), noise=0.02):
+    """Grayscale [n,1,h,w] pairs in [0,1] for the LoFTR `Matcher` (the drivers feed 256x256 crops,
+    eval_linemod_json.py:103-111): image1 = roll(image0, shift) + noise, h and w multiples of 8."""
+    g = torch.Generator().manual_seed(seed)
+    # low-pass random texture: LoFTR's CNN sees structure rather than white noise
+    base = torch.rand(n_pairs, 1, h // 4, w // 4, generator=g, dtype=torch.float32)
+    img0 = torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear", align_corners=False)
+    img0 = (0.7 * img0 + 0.3 * torch.rand(n_pairs, 1, h, w, generator=g, dtype=torch.float32)).clamp_(0, 1)
+    img1 = torch.roll(img0, shifts=shift, dims=(2, 3))
+    if noise > 0:
+        img1 = (img1 + noise * torch.randn(img1.shape, generator=g, dtype=torch.float32)).clamp_(0, 1)
+    return img0.contiguous(), img1.contiguous()

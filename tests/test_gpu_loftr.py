@@ -1,0 +1,125 @@
+"""GPU: the drop-in LoFTR `Matcher` (src/matcher/matcher.py:29-79) end to end on the card — HIP coarse
+matcher inside PyTorch-ROCm CNN/transformer plumbing — against fixtures produced by the reference's own
+Matcher.  Index parity is bit-exact wherever the coarse features are the fixture's; end to end the features
+come from MIOpen/rocBLAS instead of the CPU kernels, so floats carry a tolerance and a match may only
+differ where the reference's own confidence is within that tolerance of the threshold or of a tie."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FEAT_TOL = dict(rtol=2e-3, atol=2e-3)
+
+
+@pytest.fixture(scope="module")
+def dev(hip_lib):
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def build(thr, dev):
+    from pope_amd import synth
+    from pope_amd.matcher import Matcher, default_cfg
+    cfg = copy.deepcopy(default_cfg)
+    cfg["match_coarse"]["thr"] = float(thr)
+    m = Matcher(cfg).eval()
+    m.load_state_dict(synth.synthetic_matcher_state_dict(seed=0), strict=True)
+    return m.to(dev)
+
+
+def inputs(fx, dev):
+    from pope_amd import synth
+    n, s0, s1 = int(fx["n"]), tuple(int(v) for v in fx["shape0"]), tuple(int(v) for v in fx["shape1"])
+    i0, i1 = synth.synthetic_gray_pairs(n, *s0, seed=21)
+    if s1 != s0:
+        i1 = synth.synthetic_gray_pairs(n, *s1, seed=22)[0]
+        i1[:, :, 32:224, :] = i0[:, :, :, 32:224]
+    return i0.to(dev), i1.to(dev)
+
+
+@pytest.mark.parametrize("name", ["loftr_256_lowthr", "loftr_192x256_vs_256x192"])
+def test_coarse_stage_on_fixture_features_is_index_exact(dev, golden_dir, name):
+    """HIP CoarseMatching on the reference's own coarse features: identical (b, i, j), ordering included."""
+    from pope_amd.matcher import CoarseMatching, default_cfg
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = dict(default_cfg["match_coarse"], thr=float(fx["thr"]))
+    data = {"hw0_i": tuple(fx["shape0"]), "hw1_i": tuple(fx["shape1"]), "hw0_c": tuple(fx["hw0_c"]), "hw1_c": tuple(fx["hw1_c"])}
+    f0, f1 = torch.from_numpy(fx["feat_c0_b0"])[None].to(dev), torch.from_numpy(fx["feat_c1_b0"])[None].to(dev)
+    CoarseMatching(cfg).eval()(f0, f1, data)
+    sel = fx["b_ids"] == 0
+    assert sel.sum() > 10
+    assert np.array_equal(data["i_ids"].cpu().numpy(), fx["i_ids"][sel])
+    assert np.array_equal(data["j_ids"].cpu().numpy(), fx["j_ids"][sel])
+    np.testing.assert_allclose(data["mconf"].cpu().numpy(), fx["mconf"][sel], rtol=1e-4, atol=1e-7)
+    assert np.array_equal(data["mkpts0_c"].cpu().numpy(), fx["mkpts0_c"][sel])
+    assert np.array_equal(data["mkpts1_c"].cpu().numpy(), fx["mkpts1_c"][sel])
+    conf = data["conf_matrix"][0]
+    assert np.array_equal(conf.max(1)[1].cpu().numpy(), fx["conf_rowarg"][0])
+    assert np.array_equal(conf.max(0)[1].cpu().numpy(), fx["conf_colarg"][0])
+
+
+@pytest.mark.parametrize("name", ["loftr_256", "loftr_256_lowthr", "loftr_192x256_vs_256x192"])
+def test_matcher_end_to_end(dev, golden_dir, name):
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = build(fx["thr"], dev)
+    i0, i1 = inputs(fx, dev)
+    data = {"image0": i0, "image1": i1}
+    assert m(data) is None                         # in-place protocol (matcher.py:29)
+    for k in ("bs", "hw0_i", "hw1_i", "hw0_c", "hw1_c", "hw0_f", "hw1_f", "conf_matrix", "b_ids", "i_ids", "j_ids",
+              "gt_mask", "m_bids", "mkpts0_c", "mkpts1_c", "mconf", "W", "expec_f", "mkpts0_f", "mkpts1_f"):
+        assert k in data, k
+    assert tuple(data["hw0_c"]) == tuple(fx["hw0_c"]) and tuple(data["hw1_f"]) == tuple(fx["hw1_f"]) and data["W"] == 5
+    thr = float(fx["thr"])
+    # matches whose reference confidence is clear of the threshold must be reproduced exactly
+    ref = {(int(b), int(i)): (int(j), float(c), k) for k, (b, i, j, c) in
+           enumerate(zip(fx["b_ids"], fx["i_ids"], fx["j_ids"], fx["mconf"]))}
+    got = {(int(b), int(i)): (int(j), float(c), k) for k, (b, i, j, c) in
+           enumerate(zip(data["b_ids"].cpu().numpy(), data["i_ids"].cpu().numpy(), data["j_ids"].cpu().numpy(),
+                         data["mconf"].cpu().numpy()))}
+    margin = 0.05 * thr + 1e-4
+    for key, (j, c, _) in ref.items():
+        if c > thr + margin:
+            assert key in got and got[key][0] == j, key
+    for key, (j, c, _) in got.items():
+        assert key in ref or c < thr + margin, key
+    common = sorted(set(ref) & set(got))
+    assert len(common) >= 0.9 * len(ref) > 0
+    ri, gi = [ref[k][2] for k in common], [got[k][2] for k in common]
+    np.testing.assert_allclose(data["mconf"].cpu().numpy()[gi], fx["mconf"][ri], rtol=3e-2, atol=1e-4)
+    assert np.array_equal(data["mkpts0_c"].cpu().numpy()[gi], fx["mkpts0_c"][ri])
+    assert np.array_equal(data["mkpts0_f"].cpu().numpy()[gi], fx["mkpts0_f"][ri])
+    np.testing.assert_allclose(data["mkpts1_f"].cpu().numpy()[gi], fx["mkpts1_f"][ri], rtol=0, atol=2e-2)   # pixels
+    np.testing.assert_allclose(data["expec_f"].cpu().numpy()[gi], fx["expec_f"][ri], rtol=0, atol=5e-3)
+    # ordering: (b, i) ascending like torch.where (coarse_matching.py:193)
+    order = data["b_ids"].cpu().numpy().astype(np.int64) * 10 ** 6 + data["i_ids"].cpu().numpy()
+    assert np.all(np.diff(order) > 0)
+
+
+def test_only_att_fea_and_feature_parity(dev, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "loftr_256_lowthr.npz"))
+    m = build(fx["thr"], dev)
+    i0, i1 = inputs(fx, dev)
+    f0, f1 = m({"image0": i0, "image1": i1}, only_att_fea=True)     # matcher.py:67-68
+    assert f0.shape == (2, 1024, 256)
+    np.testing.assert_allclose(f0[:, ::8].cpu().numpy(), fx["feat_c0"], **FEAT_TOL)
+    np.testing.assert_allclose(f1[:, ::8].cpu().numpy(), fx["feat_c1"], **FEAT_TOL)
+    bc, bf = m.backbone(torch.cat([i0, i1], 0))
+    np.testing.assert_allclose(bc[:1, :, ::2, ::2].cpu().numpy(), fx["backbone_c"], **FEAT_TOL)
+    np.testing.assert_allclose(bf[:1, ::4, ::8, ::8].cpu().numpy(), fx["backbone_f"], **FEAT_TOL)
+
+
+def test_no_coarse_match_short_circuit(dev):
+    """thr above every confidence: M = 0, fine stage skipped, *_f alias *_c (fine_matching.py:33-41)."""
+    from pope_amd import synth
+    m = build(0.999999, dev)
+    i0, _ = synth.synthetic_gray_pairs(1, 64, 96, seed=2)
+    i1, _ = synth.synthetic_gray_pairs(1, 64, 96, seed=3)
+    data = {"image0": i0.to(dev), "image1": i1.to(dev)}
+    m(data)
+    assert data["b_ids"].numel() == 0 and data["expec_f"].shape == (0, 3)
+    assert data["mkpts0_f"].shape == (0, 2) and data["mkpts1_f"].shape == (0, 2)
+    assert data["conf_matrix"].shape == (1, 96, 96)
