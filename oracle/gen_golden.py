@@ -156,6 +156,58 @@ def gen_loftr():
                  hw1_f=np.array(data["hw1_f"]))
 
 
+def gen_driver():
+    """tests/golden/driver_pair.npz: the drivers' per-pair step (eval_linemod_json.py:65-127,150) executed with the
+    reference's own DINOv2 and Matcher modules on synthetic proposals (SAM / cv2 are not run: SURVEY.md §8 a-18)."""
+    import torch.nn.functional as F
+    from oracle import driver_ref
+    from pope_amd.matcher import default_cfg as my_cfg
+    vit_sd = synth.synthetic_state_dict(seed=0)
+    m_sd = synth.synthetic_matcher_state_dict(seed=0)
+    vit = load_reference_vit(vit_sd)
+    matcher, _ = load_reference_matcher()
+    matcher.load_state_dict({k: v.clone() for k, v in m_sd.items()}, strict=True)
+    ref_t, crops_t, gray_ref, gray_crops = synth.synthetic_driver_case()
+    with torch.no_grad():
+        ref_fea = vit(ref_t)                                    # get_cls_token_torch, dinov2_utils.py:106-111
+        similarity_score, top_images = np.array([0, 0, 0], np.float32), [[], [], []]
+        scores = []
+        for p in range(crops_t.shape[0]):
+            fea = vit(crops_t[p:p + 1])
+            score = F.cosine_similarity(ref_fea, fea, dim=1, eps=1e-8)
+            scores.append(score.item())
+            if (score.item() > similarity_score).any():
+                min_idx = np.argmin(similarity_score)
+                similarity_score[min_idx] = score.item()
+                top_images[min_idx] = {"proposal": p}
+        matching_score = [[0] for _ in range(len(top_images))]
+        for top_idx in range(len(top_images)):
+            p = top_images[top_idx]["proposal"]
+            batch = {"image0": gray_ref, "image1": gray_crops[p:p + 1]}
+            matcher(batch)
+            confidences = batch["mconf"].cpu().numpy()
+            matching_score[top_idx] = np.where(confidences > 0.9)[0].shape[0]
+            top_images[top_idx].update(mkpts0=batch["mkpts0_f"].numpy(), mkpts1=batch["mkpts1_f"].numpy(), mconf=confidences)
+        max_match_idx = int(np.argmax(matching_score))
+    mine = driver_ref.locate_and_match(vit_sd, m_sd, my_cfg, ref_t, crops_t, gray_ref, gray_crops)
+    assert np.array_equal(mine["slot_index"], [t["proposal"] for t in top_images])
+    assert np.array_equal(mine["slot_scores"], similarity_score) and np.array_equal(mine["scores"], np.array(scores, np.float32))
+    assert list(mine["matching_score"]) == matching_score and mine["best_slot"] == max_match_idx
+    for s in range(3):
+        for k in ("mkpts0", "mkpts1", "mconf"):
+            assert np.array_equal(mine[k][s], top_images[s][k]), (s, k)
+    print("driver_pair: scores", np.round(scores, 4), "slots", [t["proposal"] for t in top_images], similarity_score,
+          "matching_score", matching_score, "best slot", max_match_idx)
+    assert len(set(matching_score)) > 1 and max(matching_score) > 0
+    fx = {"scores": np.array(scores, np.float32), "slot_scores": similarity_score,
+          "slot_index": np.array([t["proposal"] for t in top_images]), "matching_score": np.array(matching_score),
+          "best_slot": max_match_idx}
+    for s in range(3):
+        for k in ("mkpts0", "mkpts1", "mconf"):
+            fx[f"{k}_{s}"] = top_images[s][k]
+    np.savez(os.path.join(OUT, "driver_pair.npz"), **fx)
+
+
 def sd_digest(sd):
     return np.array([float(sd[k].double().sum()) for k in sorted(sd)], np.float64)
 
@@ -185,6 +237,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-loftr" in sys.argv:
         return gen_loftr()
+    if "--only-driver" in sys.argv:
+        return gen_driver()
     sd = synth.synthetic_state_dict(seed=0)
     assert len(sd) == 175
     model = load_reference_vit(sd)
@@ -293,6 +347,7 @@ def main():
     np.savez(os.path.join(OUT, "top3.npz"), ref=ref.numpy(), fea=fea.numpy(), scores=scores.numpy(),
              slot_scores=slots, slot_index=np.array(top))
     gen_loftr()
+    gen_driver()
     print("golden fixtures written to", OUT)
 
 

@@ -32,6 +32,17 @@ constexpr int STAGE = 4 * PLANE;                // A hi, A lo, W hi, W lo
 constexpr size_t X3_LDS_BYTES = size_t(2) * STAGE * sizeof(_Float16);
 static_assert(X3_LDS_BYTES >= size_t(4) * 32 * EPI_ST * sizeof(float), "epilogue staging must fit");
 
+// Planes kernel: LDS rows keep the memory layout of a K-step, [32 hi | 32 lo] halves + 16 B pad = 144 B.
+// The eight lanes that fetch one row's 128 contiguous bytes also write 128 contiguous LDS bytes (all 32
+// store banks once: the separate-plane layout above put the hi and lo pieces on the same banks, a 2-way
+// conflict on every ds_write_b128 — 8.7 conflict cycles per store in the PMC run), and the 36-dword row
+// stride keeps the 16 rows of a ds_read_b128 lane group on 16 distinct 4-bank sets.
+constexpr int ROW2 = 72;                        // halves per LDS row
+constexpr int OPER2 = 128 * ROW2;               // halves per operand tile (128 rows, both planes)
+constexpr int STAGE2 = 2 * OPER2;               // A, W
+constexpr size_t X3P_LDS_BYTES = size_t(2) * STAGE2 * sizeof(_Float16);
+static_assert(size_t(STAGE2) * sizeof(_Float16) >= size_t(4) * 32 * EPI_ST * sizeof(float), "epilogue staging must fit a stage");
+
 constexpr float A_SCALE = 8.0f, W_SCALE = 256.0f;  // powers of two: exact
 
 __device__ __forceinline__ void split(f32x4 v, float scale, f16x4& hi, f16x4& lo) {
@@ -208,13 +219,11 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
     // Staging: a row's K-step is 128 contiguous bytes in memory ([32 hi | 32 lo] halves) = eight 16-byte
-    // pieces = eight consecutive lanes -> whole cache lines.  Thread -> rows prow + 32 i (i < 4), piece pc
-    // (plane pc>>2, 16-byte column pc&3).  The row order is permuted so that the rows written by one
-    // 8-lane ds_write_b128 group (two rows x one plane... consecutive slots) are 4 apart: their 64-byte
-    // bank ranges are 16 banks apart with the 80-byte row stride (conflict-free).
+    // pieces = eight consecutive lanes -> whole cache lines, and the same 128 contiguous bytes in LDS.
+    // Thread -> rows prow + 32 i (i < 4), piece pc.
     const int slot = tid >> 3, pc = tid & 7;
     const int prow = ((slot >> 1) & 3) + 4 * (slot & 1) + 8 * (slot >> 3);  // bijection on 0..31
-    const int lds_piece = (pc >> 2) * PLANE + 8 * (pc & 3);
+    const int lds_piece = 8 * pc;
     const int nk = g.K / BK;  // >= 2 (launcher)
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, unsigned(g.M) * unsigned(g.lda) * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, unsigned(g.N) * unsigned(g.ldw) * 4u, 0x00020000);
@@ -248,14 +257,14 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
         }
     };
     auto write_stage = [&](int s, const u32x4 (&st)[8]) {
-        _Float16* S = lds + s * STAGE + lds_piece;
+        _Float16* S = lds + s * STAGE2 + lds_piece;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(S + (prow + 32 * i) * PL_ST) = st[i];
-            *reinterpret_cast<u32x4*>(S + 2 * PLANE + (prow + 32 * i) * PL_ST) = st[4 + i];
+            *reinterpret_cast<u32x4*>(S + (prow + 32 * i) * ROW2) = st[i];
+            *reinterpret_cast<u32x4*>(S + OPER2 + (prow + 32 * i) * ROW2) = st[4 + i];
         }
     };
-    const int a_off = (wm * 64 + r) * PL_ST + 8 * h, w_off = 2 * PLANE + (wn * 64 + r) * PL_ST + 8 * h;
+    const int a_off = (wm * 64 + r) * ROW2 + 8 * h, w_off = OPER2 + (wn * 64 + r) * ROW2 + 8 * h;
     f32x16 acc[2][2];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -267,13 +276,13 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     };
     struct Frags { f16x8 ah[2], al[2], wh[2], wl[2]; };
     auto read_frags = [&](int s, int kg, Frags& f) {
-        const _Float16* S = lds + s * STAGE;
+        const _Float16* S = lds + s * STAGE2;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f.ah[t] = *reinterpret_cast<const f16x8*>(S + a_off + t * 32 * PL_ST + kg * 16);
-            f.al[t] = *reinterpret_cast<const f16x8*>(S + PLANE + a_off + t * 32 * PL_ST + kg * 16);
-            f.wh[t] = *reinterpret_cast<const f16x8*>(S + w_off + t * 32 * PL_ST + kg * 16);
-            f.wl[t] = *reinterpret_cast<const f16x8*>(S + PLANE + w_off + t * 32 * PL_ST + kg * 16);
+            f.ah[t] = *reinterpret_cast<const f16x8*>(S + a_off + t * 32 * ROW2 + kg * 16);
+            f.al[t] = *reinterpret_cast<const f16x8*>(S + 32 + a_off + t * 32 * ROW2 + kg * 16);
+            f.wh[t] = *reinterpret_cast<const f16x8*>(S + w_off + t * 32 * ROW2 + kg * 16);
+            f.wl[t] = *reinterpret_cast<const f16x8*>(S + 32 + w_off + t * 32 * ROW2 + kg * 16);
         }
     };
     auto mfma_frags = [&](const Frags& f) {
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
 #endif
         __syncthreads();  // stage (s+1)&1 is published, stage s&1 is free
         if (++kt == nk) {
-            epilogue(tile, reinterpret_cast<float*>(lds + (s & 1) * STAGE));
+            epilogue(tile, reinterpret_cast<float*>(lds + (s & 1) * STAGE2));
             zero_acc();
             kt = 0;
             tile += stride;
@@ -429,14 +438,14 @@ int launch_planes(const GemmParams& g, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f16x3_planes_kernel<EPI, OUT_PLANES>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(X3_LDS_BYTES)) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(X3P_LDS_BYTES)) != hipSuccess)
             return POPE_ERR_LAUNCH;
         attr_set = true;
     }
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    const int slots = 2 * pope_cu_count();  // two resident workgroups per CU (2 x 80 KB LDS)
+    const int slots = 2 * pope_cu_count();  // two resident workgroups per CU (2 x 72 KB LDS, 128 VGPRs + 64 AGPRs)
     hipLaunchKernelGGL((gemm_nt_f16x3_planes_kernel<EPI, OUT_PLANES>), dim3(tiles < slots ? tiles : slots), dim3(THREADS),
-                       X3_LDS_BYTES, stream, g, tiles);
+                       X3P_LDS_BYTES, stream, g, tiles);
     return pope_check_launch();
 }
 

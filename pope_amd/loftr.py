@@ -96,6 +96,7 @@ class ResNetFPN_8_2(nn.Module):
         self._folded = None
         return super()._apply(fn, *a, **k)
 
+    @torch.no_grad()
     def forward(self, x):
         if self.training:
             raise NotImplementedError("pope_amd: inference only (BatchNorm is folded; call .eval())")

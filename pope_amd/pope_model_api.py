@@ -1,7 +1,7 @@
 """Hot-path subset of the reference façade `pope_model_api.py` (star-imported by the drivers,
 eval_linemod_json.py:1).  Exports, under the reference's names, everything of that namespace that
 lies on the accelerated path; names that belong to out-of-scope stages (SAM proposal
-generator, OpenCV pose solver, LoFTR CNN stages) are not re-implemented here — the reference's own
+generator, OpenCV pose solver, cv2 cropping helpers) are not re-implemented here — the reference's own
 modules keep providing them.
 
 Unlike the reference façade, importing this module has no side effects (the reference builds the
@@ -16,9 +16,21 @@ import torch  # noqa: F401
 import torch.nn.functional as F  # noqa: F401
 
 from .dinov2_utils import get_cls_token_torch, load_dinov2_model, set_torch_image  # noqa: F401
-from .matcher import CoarseMatching, default_cfg, dense_match  # noqa: F401
+from .driver import locate_and_match  # noqa: F401
+from .matcher import CoarseMatching, Matcher, default_cfg, dense_match  # noqa: F401
 from .ops import cls_cosine, streaming_top3  # noqa: F401
 from .pipeline import PairPipeline, gather_counts, shard_range  # noqa: F401
+
+
+def build_matcher(weights="weights/matcher.pth", device="cuda:0", state_dict=None):
+    """The module-level `matcher` singleton of the reference façade (pope_model_api.py:177-185: Matcher(default_cfg),
+    `torch.load("weights/matcher.pth")['state_dict']` loaded with strict=False, .eval(), moved to a GPU) as an
+    explicit call; `state_dict` overrides the file (synthetic weights in tests)."""
+    matcher = Matcher(default_cfg)
+    if state_dict is None:
+        state_dict = torch.load(weights, map_location="cpu")["state_dict"]
+    matcher.load_state_dict(state_dict, strict=False)
+    return matcher.eval().to(device)
 
 
 def vote_top3(model, ref_tensor, crop_tensors):

@@ -166,3 +166,23 @@ def synthetic_gray_pairs(n_pairs, h=256, w=256, seed=0, shift=(8, 16), noise=0.0
     if noise > 0:
         img1 = (img1 + noise * torch.randn(img1.shape, generator=g, dtype=torch.float32)).clamp_(0, 1)
     return img0.contiguous(), img1.contiguous()
+
+
+def synthetic_driver_case(n_proposals=8, seed=31):
+    """Synthetic stand-in for one iteration of the drivers' pair loop (eval_linemod_json.py:52-127) without
+    SAM / cv2: a reference crop, P proposal crops for DINOv2 (196x196, the drivers' centre-crop size) and the
+    matching gray images for LoFTR (256x256).  Proposals 2, 5 and 6 show the reference object (shifted,
+    increasingly noisy), proposal 3 duplicates proposal 2's DINOv2 crop exactly (a score tie), the others
+    are unrelated texture."""
+    g = torch.Generator().manual_seed(seed)
+    ref_tensor = synthetic_images(1, 196, 196, seed=seed)
+    crop_tensors = synthetic_images(n_proposals, 196, 196, seed=seed + 1)
+    gray_ref = synthetic_gray_pairs(1, 256, 256, seed=seed)[0]
+    gray_crops = synthetic_gray_pairs(n_proposals, 256, 256, seed=seed + 2)[0]
+    for p, (noise_rgb, shift, noise_gray) in {2: (0.3, (8, 16), 0.01), 5: (0.6, (16, 8), 0.03),
+                                              6: (1.0, (24, 24), 0.06)}.items():
+        crop_tensors[p] = ref_tensor[0] + noise_rgb * torch.randn(ref_tensor[0].shape, generator=g)
+        gray_crops[p] = (torch.roll(gray_ref[0], shifts=shift, dims=(1, 2))
+                         + noise_gray * torch.randn(gray_ref[0].shape, generator=g)).clamp_(0, 1)
+    crop_tensors[3] = crop_tensors[2]
+    return ref_tensor, crop_tensors, gray_ref, gray_crops

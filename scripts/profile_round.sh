@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round profile on the GPU box: rocprofv3 kernel stats of the bench command, then PMC passes (each in its own
+# run, counters only — never combined with trace domains) on the 64-image forward driver.
+# Usage: bash scripts/profile_round.sh   (from the repo root; writes under gpurun_out/)
+set -e -o pipefail
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_profiled.json
+echo "stats pass done"
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" \
+            "TCC_HIT_sum TCC_MISS_sum"; do
+    tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
+    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$tag -o pmc -- python3 $ROOT/scripts/prof_forward.py 64 2 > $OUT/pmc_$tag.log
+    echo "pmc pass $tag done"
+done
+cd $ROOT
+python3 scripts/pmc_summary.py $(find $OUT/pmc_* -name '*counter_collection.csv') > $OUT/pmc_summary.txt
+# keep the summaries only: the raw traces exceed what gpurun copies back
+mkdir -p $OUT/profile_round
+cp $(find $OUT/prof_stats -name '*kernel_stats.csv') $OUT/profile_round/bench_kernel_stats.csv
+mv $OUT/pmc_summary.txt $OUT/bench_profiled.json $OUT/profile_round/
+rm -rf $OUT/prof_stats $OUT/pmc_*
+echo "profile_round done"

@@ -1,0 +1,62 @@
+"""GPU: the batched per-pair driver step (pope_amd/driver.py) against the fixture captured from the
+reference's sequential loop (eval_linemod_json.py:65-127,150)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(hip_lib):
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def models(dev, sd0):
+    from pope_amd import synth
+    from pope_amd.dinov2_utils import load_dinov2_model
+    from pope_amd.matcher import Matcher, default_cfg
+    vit = load_dinov2_model(state_dict=sd0).to(dev)
+    matcher = Matcher(default_cfg).eval()
+    matcher.load_state_dict(synth.synthetic_matcher_state_dict(seed=0), strict=True)
+    return vit, matcher.to(dev)
+
+
+def test_driver_step_matches_reference_loop(dev, models, golden_dir):
+    from pope_amd import synth
+    from pope_amd.driver import locate_and_match
+    fx = np.load(os.path.join(golden_dir, "driver_pair.npz"))
+    vit, matcher = models
+    out = locate_and_match(vit, matcher, *(t.to(dev) for t in synth.synthetic_driver_case()))
+    np.testing.assert_allclose(out["scores"].cpu().numpy(), fx["scores"], rtol=0, atol=2e-5)
+    assert np.array_equal(out["slot_index"], fx["slot_index"])
+    np.testing.assert_allclose(out["slot_scores"], fx["slot_scores"], rtol=0, atol=2e-5)
+    for s in range(3):
+        ref_c, got_c = fx[f"mconf_{s}"], out["mconf"][s]
+        clear = np.abs(ref_c - 0.2) > 0.01              # matches whose confidence is clear of the threshold
+        assert abs(len(got_c) - len(ref_c)) <= int((~clear).sum())
+        if len(got_c) == len(ref_c):
+            np.testing.assert_allclose(got_c, ref_c, rtol=3e-2, atol=1e-4)
+            np.testing.assert_allclose(out["mkpts1"][s], fx[f"mkpts1_{s}"], rtol=0, atol=2e-2)
+            assert np.array_equal(out["mkpts0"][s], fx[f"mkpts0_{s}"])
+        near = int((np.abs(ref_c - 0.9) < 0.01).sum())    # matching_score counts mconf > 0.9
+        assert abs(int(out["matching_score"][s]) - int(fx["matching_score"][s])) <= near
+    if all(int((np.abs(fx[f"mconf_{s}"] - 0.9) < 0.01).sum()) == 0 for s in range(3)):
+        assert np.array_equal(out["matching_score"], fx["matching_score"])
+        assert out["best_slot"] == int(fx["best_slot"]) and out["best_proposal"] == int(fx["slot_index"][fx["best_slot"]])
+
+
+def test_driver_step_with_fewer_than_three_candidates(dev, models):
+    """Slots that never fill are skipped (the reference would raise at eval_linemod_json.py:109)."""
+    from pope_amd import synth
+    from pope_amd.driver import locate_and_match
+    vit, matcher = models
+    ref_t, crops_t, gray_ref, gray_crops = (t.to(dev) for t in synth.synthetic_driver_case())
+    out = locate_and_match(vit, matcher, ref_t, crops_t[2:3], gray_ref, gray_crops[2:3])
+    assert list(out["slot_index"]) == [0, -1, -1]
+    assert out["matching_score"][1] == 0 and out["matching_score"][2] == 0 and out["mconf"][1].shape == (0,)
+    assert out["best_slot"] == 0 and out["best_proposal"] == 0 and len(out["mconf"][0]) > 0
