@@ -69,6 +69,7 @@ int pope_split_planes_f32(const float* src, void* planes, int rows, int cols, fl
 int pope_linear_planes_f32(const void* a_planes, const void* w_planes, const float* bias, float* C,
                            void* c_planes, int M, int N, int K, int epilogue, const float* gamma,
                            const float* res, void* stream);
+
 /* LayerNorm written as activation planes [rows, dim]. */
 int pope_layernorm_planes_f32(const float* x, const float* weight, const float* bias, void* y_planes,
                               int rows, int dim, float eps, void* stream);
@@ -138,6 +139,16 @@ int pope_vit_forward_profiled_f32(const pope_vit_weights* w_host, const float* i
                                   void* workspace, size_t workspace_bytes, void* stream,
                                   void* const* events_host, int n_events, int* kinds_host,
                                   int* n_launches_host);
+/* Same, but only launches whose POPE_K_* bit is set in kind_mask are bracketed (an event before and one after
+ * each): timing one kernel kind leaves every other launch of the sequence back to back, as in the untimed
+ * path.  events_host[i] / kinds_host[i] then hold the recorded events in order; kinds_host[i] is the kind
+ * of the launch that STARTS at event i, or -1 for an event that only closes the previous bracket;
+ * *n_launches_host = number of recorded events - 1. */
+int pope_vit_forward_profiled_mask_f32(const pope_vit_weights* w_host, const float* img, int B, int H, int W,
+                                       const float* posb, float* x_prenorm, float* x_norm,
+                                       void* workspace, size_t workspace_bytes, void* stream,
+                                       void* const* events_host, int n_events, int* kinds_host,
+                                       int* n_launches_host, unsigned kind_mask);
 int pope_event_create(void** event_host);
 int pope_event_destroy(void* event);
 int pope_event_elapsed_ms(void* start, void* stop, float* ms_host);  /* both events must have completed */

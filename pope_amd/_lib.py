@@ -53,6 +53,10 @@ PROTOTYPES = {
     "pope_vit_forward_profiled_f32": (C.c_int, [C.POINTER(VitWeights), C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                                 C.POINTER(C.c_void_p), C.c_int, c_int_p, c_int_p]),
+    "pope_vit_forward_profiled_mask_f32": (C.c_int, [C.POINTER(VitWeights), C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                     C.c_void_p, C.POINTER(C.c_void_p), C.c_int, c_int_p, c_int_p,
+                                                     C.c_uint]),
     "pope_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "pope_event_destroy": (C.c_int, [C.c_void_p]),
     "pope_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, c_float_p]),

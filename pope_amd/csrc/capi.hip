@@ -10,16 +10,23 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Optional in-situ timing: events[i] is recorded on the stream right before launch i and one more
 // after the last launch, so events[i]..events[i+1] bracket exactly one kernel of the product path.
+// With a kind mask only the selected launches are bracketed: an event is recorded when the coming launch is
+// selected (it starts a bracket) or the previous one was (it closes one); kinds[i] = -1 marks close-only events.
 struct Recorder {
     void* const* events;
     int capacity;
     int* kinds;
     int n;
+    unsigned mask = ~0u;
+    bool open = false;
     bool mark(int kind, hipStream_t stream) {
         if (!events) return true;
+        const bool sel = kind >= 0 && ((mask >> kind) & 1u);
+        if (!sel && !open) return true;
         if (n >= capacity) return false;
         if (hipEventRecord(static_cast<hipEvent_t>(events[n]), stream) != hipSuccess) return false;
-        if (kinds && kind >= 0) kinds[n] = kind;
+        if (kinds) kinds[n] = sel ? kind : -1;
+        open = sel;
         ++n;
         return true;
     }
@@ -253,21 +260,30 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
 int pope_vit_forward_f32(const pope_vit_weights* w, const float* img, int B, int H, int W, const float* posb,
                          float* x_prenorm, float* x_norm, int n_taps, const int* tap_blocks_host,
                          float* const* tap_out_host, void* workspace, size_t workspace_bytes, void* stream) {
-    Recorder rec = {nullptr, 0, nullptr, 0};
+    Recorder rec{nullptr, 0, nullptr, 0};
     return vit_forward_impl(w, img, B, H, W, posb, x_prenorm, x_norm, n_taps, tap_blocks_host, tap_out_host, workspace,
                             workspace_bytes, stream, rec);
+}
+
+int pope_vit_forward_profiled_mask_f32(const pope_vit_weights* w, const float* img, int B, int H, int W,
+                                       const float* posb, float* x_prenorm, float* x_norm, void* workspace,
+                                       size_t workspace_bytes, void* stream, void* const* events_host, int n_events,
+                                       int* kinds_host, int* n_launches_host, unsigned kind_mask) {
+    if (!events_host || n_events < 2 || !kinds_host || !n_launches_host) return POPE_ERR_ARG;
+    Recorder rec{events_host, n_events, kinds_host, 0};
+    rec.mask = kind_mask;
+    const int rc = vit_forward_impl(w, img, B, H, W, posb, x_prenorm, x_norm, 0, nullptr, nullptr, workspace,
+                                    workspace_bytes, stream, rec);
+    *n_launches_host = rec.n > 0 ? rec.n - 1 : 0;
+    return rc;
 }
 
 int pope_vit_forward_profiled_f32(const pope_vit_weights* w, const float* img, int B, int H, int W, const float* posb,
                                   float* x_prenorm, float* x_norm, void* workspace, size_t workspace_bytes,
                                   void* stream, void* const* events_host, int n_events, int* kinds_host,
                                   int* n_launches_host) {
-    if (!events_host || n_events < 2 || !kinds_host || !n_launches_host) return POPE_ERR_ARG;
-    Recorder rec = {events_host, n_events, kinds_host, 0};
-    const int rc = vit_forward_impl(w, img, B, H, W, posb, x_prenorm, x_norm, 0, nullptr, nullptr, workspace,
-                                    workspace_bytes, stream, rec);
-    *n_launches_host = rec.n > 0 ? rec.n - 1 : 0;
-    return rc;
+    return pope_vit_forward_profiled_mask_f32(w, img, B, H, W, posb, x_prenorm, x_norm, workspace, workspace_bytes, stream,
+                                              events_host, n_events, kinds_host, n_launches_host, ~0u);
 }
 
 int pope_vit_launch_count(int depth) { return depth > 0 ? 7 * depth + 2 : 0; }

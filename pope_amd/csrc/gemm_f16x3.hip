@@ -203,6 +203,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_kernel(const GemmPar
 // epilogue, the weight loader), so the K loop is loads -> ds_write_b128 -> ds_read_b128 -> MFMA with
 // no VALU work at all; the epilogue can emit planes for the next GEMM.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 // Persistent: two workgroups per CU walk the tile list (logical id = xcd_remap(blockIdx) + i*grid:
 // an XCD keeps whole A row panels in its L2) and treat the K-steps of consecutive tiles as ONE
@@ -232,6 +233,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     // written to the other stage: the CU has ~128 KB of loads outstanding, which is what it takes to
     // cover the L2 round trip at this tile size (one set = 64 KB in flight measured ~23 B/clk/CU).
     u32x4 r0[8], r1[8];  // A rows 0..3, W rows 0..3
+    // Tile order: static round robin over the XCD-remapped workgroup id.  (The two workgroups of a CU do not
+    // progress evenly — the first-dispatched one runs ~1.4x faster and the other finishes its share alone — but
+    // neither an atomic tile queue nor an unequal static split shortened the launch: DESIGN.md §4, finding 4.)
     const int stride = gridDim.x;
     const int first = xcd_remap(blockIdx.x, gridDim.x);
     if (first >= n_tiles) return;
@@ -295,46 +299,91 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
                 acc[mi][ni] = mfma_f16(f.wh[ni], f.ah[mi], acc[mi][ni]);
             }
     };
+    // Epilogue of one tile, branch-free and free of loads between its stores: bias / gamma are per-lane
+    // constants of the tile (a lane keeps its four columns for all 16 row pieces) and are fetched once, up
+    // front, under the LDS transposition; rows >= M and columns >= N are dropped by the buffer descriptor's
+    // range check instead of exec-mask branches.  (The first version loaded bias inside every piece: the
+    // compiler then has to drain vmcnt to 0 before each store — loads and stores share the counter and may
+    // retire out of order — so every one of the 16 stores waited for the previous store to reach memory.)
+    // The residual variant needs one load per piece: fetched eight at a time, two drain points per tile.
+    const unsigned c_row_bytes = unsigned(g.ldc) * 4u;  // fp32 rows and planes rows have the same pitch
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+        OUT_PLANES ? g.c_pl : static_cast<void*>(g.C), 0, unsigned(g.M) * c_row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(EPI == EPI_BIAS_LS_RES ? g.res : g.C), 0,
+        EPI == EPI_BIAS_LS_RES ? unsigned(g.M) * unsigned(g.ldres) * 4u : 0u, 0x00020000);
+    const int ec4 = (lane & 15) * 4, elr = lane >> 4;
     auto epilogue = [&](int tile, float* epi) {
         const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+        const int col = n0 + wn * 64 + ec4;
+        const bool col_ok = col < g.N;
+        const int colc = col_ok ? col : 0;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, gamma = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) bias = *reinterpret_cast<const f32x4*>(g.bias + colc);
+        if constexpr (EPI == EPI_BIAS_LS_RES) gamma = *reinterpret_cast<const f32x4*>(g.gamma + colc);
+        constexpr float inv = 1.0f / (A_SCALE * W_SCALE);
+        if constexpr (EPI == EPI_BIAS_LS_RES) {  // res + (v*inv + bias)*gamma = res + v*(inv*gamma) + bias*gamma
+            bias = bias * gamma;
+            gamma = gamma * inv;
+        }
+        constexpr unsigned DROP = 0xFFFFFF00u;  // beyond every buffer extent: the access is discarded
+        __syncthreads();  // all waves have finished reading the last K-step stage
+        float* E = epi + wave * 32 * EPI_ST;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = acc[mi][ni] * (1.0f / (A_SCALE * W_SCALE));
-        epilogue_rows(acc, epi, [&](int tr, int tc, f32x4 v) {
-            const int row = m0 + tr, col = n0 + tc;
-            if (row >= g.M || col >= g.N) return;
-            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-            if (g.bias) bias = *reinterpret_cast<const f32x4*>(g.bias + col);
-            if constexpr (EPI == EPI_BIAS) {
-                v = v + bias;
-            } else if constexpr (EPI == EPI_BIAS_GELU) {
-                v = v + bias;
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf_scalar(v[e]);
-            } else {
-                const f32x4 gamma = *reinterpret_cast<const f32x4*>(g.gamma + col);
-                const f32x4 res = *reinterpret_cast<const f32x4*>(g.res + size_t(row) * g.ldres + col);
-                v = res + (v + bias) * gamma;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g4 + e];
+                    *reinterpret_cast<f32x4*>(&E[r * EPI_ST + ni * 32 + 8 * g4 + 4 * h]) = v;
+                }
+            const unsigned row0 = unsigned(m0 + wm * 64 + mi * 32 + elr);
+            f32x4 res[8];
+            if constexpr (EPI == EPI_BIAS_LS_RES) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    res[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                 rres, col_ok ? (row0 + 4 * i) * unsigned(g.ldres) * 4u + unsigned(col) * 4u : DROP, 0, 0));
             }
-            if constexpr (OUT_PLANES) {
-                f16x4 hi, lo;
-                split(v, A_SCALE, hi, lo);
-                _Float16* o = static_cast<_Float16*>(g.c_pl) + size_t(row) * 2 * g.ldc + (col >> 5) * 64 + (col & 31);
-                __builtin_nontemporal_store(hi, reinterpret_cast<f16x4*>(o));
-                __builtin_nontemporal_store(lo, reinterpret_cast<f16x4*>(o + 32));
-            } else {
-#if defined(X3_NOSTORE)
-                if (v[0] == 1234.5678f) *reinterpret_cast<f32x4*>(g.C + size_t(row) * g.ldc + col) = v;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(&E[(elr + 4 * i) * EPI_ST + ec4]);
+                const unsigned off = (row0 + 4 * i) * c_row_bytes;
+                if constexpr (EPI == EPI_BIAS) {
+                    v = v * inv + bias;
+                } else if constexpr (EPI == EPI_BIAS_GELU) {
+                    v = v * inv + bias;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_scalar(v[e]);
+                } else {
+                    v = res[i] + v * gamma + bias;
+                }
+                if constexpr (OUT_PLANES) {
+                    f16x4 hi, lo;
+                    split(v, A_SCALE, hi, lo);
+                    // planes row: per 32-column chunk [32 hi | 32 lo] halves
+                    const unsigned o = col_ok ? off + unsigned((col >> 5) * 128 + (col & 31) * 2) : DROP;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rc, o, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rc, o + 64u, 0, 2);
+                } else {
+                    // write-once outputs (qkv: 450 MB per launch, far beyond L2) are stored non-temporally so
+                    // they do not displace the A/W panels in L2 (+5 %); the residual stream (LS_RES) is re-read
+                    // by the next LayerNorm and keeps the default policy
+#ifdef X3_NOSTORE  // dev timing experiment: every store is out of range (dropped by the descriptor)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, v[0] == 1234.5f ? 0u : DROP, 0, 0);
 #else
-                // write-once outputs (qkv: 450 MB per launch, far beyond L2) are stored non-temporally so they
-                // do not displace the A/W panels in L2 (+5 %); the residual stream (LS_RES) is re-read by
-                // the next LayerNorm and keeps the default policy
-                if constexpr (EPI == EPI_BIAS_LS_RES) *reinterpret_cast<f32x4*>(g.C + size_t(row) * g.ldc + col) = v;
-                else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g.C + size_t(row) * g.ldc + col));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc,
+                                                           col_ok ? off + unsigned(col) * 4u : DROP, 0,
+                                                           EPI == EPI_BIAS_LS_RES ? 0 : 2);
 #endif
+                }
             }
-        });
+            __builtin_amdgcn_wave_barrier();
+        }
         __syncthreads();  // epilogue staging is drained before the stage is written again
     };
 
@@ -351,7 +400,21 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     // under the ds_writes / buffer loads of the staging work; the second half's fragments are read
     // while the first half's 12 MFMAs execute (the two waves of a SIMD run in lockstep, so an LDS
     // wait of one is not covered by MFMAs of the other).
+#ifdef X3_STAMPS  // dev: cycle stamps of (block, tile ordinal, K-step) into g.posb (scripts/x3_lab.cpp)
+    int tile_ord = 0;
+    auto stamp = [&](int slot) {
+        if (tid == 0 && g.posb && tile_ord < 16 && blockIdx.x < 512)
+            reinterpret_cast<unsigned long long*>(const_cast<float*>(g.posb))[(blockIdx.x * 16 + tile_ord) * 16 + slot] =
+                __builtin_readcyclecounter();
+        if (tid == 0 && g.posb && tile_ord < 16 && blockIdx.x < 512 && (slot == 0 || slot == 13))  // 100 MHz wall clock
+            reinterpret_cast<unsigned long long*>(const_cast<float*>(g.posb))[(blockIdx.x * 16 + tile_ord) * 16 + (slot ? 15 : 14)] =
+                __builtin_amdgcn_s_memrealtime();
+    };
+#else
+    auto stamp = [&](int) {};
+#endif
     auto item = [&](int s, u32x4 (&nx)[8]) {
+        stamp(kt);
         Frags f0, f1;
         read_frags(s & 1, 0, f0);
         write_stage((s + 1) & 1, nx);
@@ -375,7 +438,12 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
 #endif
         __syncthreads();  // stage (s+1)&1 is published, stage s&1 is free
         if (++kt == nk) {
+            stamp(12);
             epilogue(tile, reinterpret_cast<float*>(lds + (s & 1) * STAGE2));
+            stamp(13);
+#ifdef X3_STAMPS
+            ++tile_ord;
+#endif
             zero_acc();
             kt = 0;
             tile += stride;
@@ -456,6 +524,9 @@ int pope_launch_gemm_nt_f16x3_planes(const GemmParams& g, hipStream_t stream) {
     if (size_t(g.M + BM) * g.lda * 4 >= (size_t(1) << 32) || size_t(g.N + BN) * g.ldw * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
     const bool out_planes = g.c_pl != nullptr;
     if (out_planes ? (g.ldc & 31) != 0 : !g.C) return POPE_ERR_ARG;
+    // the epilogue addresses C (and res) through 32-bit buffer offsets
+    if (size_t(g.M + BM) * g.ldc * 4 >= (size_t(1) << 32) - 512) return POPE_ERR_ARG;
+    if (g.epilogue == EPI_BIAS_LS_RES && size_t(g.M + BM) * g.ldres * 4 >= (size_t(1) << 32) - 512) return POPE_ERR_ARG;
     switch (g.epilogue) {
         case EPI_BIAS: return out_planes ? launch_planes<EPI_BIAS, true>(g, stream) : launch_planes<EPI_BIAS, false>(g, stream);
         case EPI_BIAS_GELU:

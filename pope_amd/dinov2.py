@@ -203,9 +203,14 @@ class DinoVisionTransformer(nn.Module):
         return self._posb_cache[key]
 
     def _workspace(self, nbytes, device):
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        return self._ws
+        """Scratch of the launch sequence, one per (device, stream): forwards on different streams may overlap."""
+        if not isinstance(self._ws, dict):
+            self._ws = {}
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return ws
 
     # ---- forward --------------------------------------------------------------------------
     def _run(self, x, taps=()):
@@ -234,9 +239,10 @@ class DinoVisionTransformer(nn.Module):
         if slot is not None:
             off, ev, cap, kinds = slot
             n_launch = C.c_int()
-            check(L.pope_vit_forward_profiled_f32(C.byref(w), ptr(x), B, H, W, ptr(posb), ptr(x_pre), ptr(x_norm),
-                                                  C.c_void_p(ws.data_ptr()), ws.numel(), stream_of(x.device), ev, cap,
-                                                  kinds, C.byref(n_launch)), "pope_vit_forward_profiled_f32")
+            check(L.pope_vit_forward_profiled_mask_f32(C.byref(w), ptr(x), B, H, W, ptr(posb), ptr(x_pre), ptr(x_norm),
+                                                       C.c_void_p(ws.data_ptr()), ws.numel(), stream_of(x.device), ev,
+                                                       cap, kinds, C.byref(n_launch), self.profiler.mask),
+                  "pope_vit_forward_profiled_mask_f32")
             self.profiler.commit(off, n_launch.value)
             return x_pre, x_norm, tap_out
         check(L.pope_vit_forward_f32(C.byref(w), ptr(x), B, H, W, ptr(posb), ptr(x_pre), ptr(x_norm),

@@ -40,18 +40,37 @@ def gather_counts(local_counts, group=None):
 class PairPipeline:
     """extract(img0), extract(img1) -> dense_match, for a batch of pairs resident on one GPU."""
 
-    def __init__(self, model, chunk=64, thr=0.2, border_rm=2, temperature=0.1):
+    def __init__(self, model, chunk=64, thr=0.2, border_rm=2, temperature=0.1, streams=1):
         self.model = model
         self.chunk = chunk
         self.thr, self.border_rm, self.temperature = thr, border_rm, temperature
+        self.n_streams = streams
+        self._streams = None
 
     @torch.no_grad()
     def extract(self, images):
-        """[B,3,H,W] -> x_norm_patchtokens [B, H/14*W/14, dim], processed `chunk` images at a time."""
+        """[B,3,H,W] -> x_norm_patchtokens [B, H/14*W/14, dim], processed `chunk` images at a time.
+        With streams > 1 consecutive chunks run on different HIP streams (own scratch each), so the
+        HBM-bound kernels and the tile-quantisation tails of one chunk overlap the MFMA phases of another."""
+        starts = list(range(0, images.shape[0], self.chunk))
+        if self.n_streams <= 1 or len(starts) == 1:
+            outs = [self.model(images[s:s + self.chunk], is_training=True)["x_norm_patchtokens"] for s in starts]
+            return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+        main = torch.cuda.current_stream(images.device)
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(images.device) for _ in range(self.n_streams)]
         outs = []
-        for s in range(0, images.shape[0], self.chunk):
-            outs.append(self.model(images[s:s + self.chunk], is_training=True)["x_norm_patchtokens"])
-        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+        for st in self._streams:
+            st.wait_stream(main)
+        for k, s in enumerate(starts):
+            st = self._streams[k % self.n_streams]
+            with torch.cuda.stream(st):
+                o = self.model(images[s:s + self.chunk], is_training=True)["x_norm_patchtokens"]
+            o.record_stream(main)
+            outs.append(o)
+        for st in self._streams:
+            main.wait_stream(st)
+        return torch.cat(outs, 0)
 
     @torch.no_grad()
     def __call__(self, img0, img1):

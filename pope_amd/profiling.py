@@ -1,8 +1,10 @@
 """In-situ per-kernel timing of the product path with HIP events (used by bench.py's roofline leg).
 
 `KernelProfiler` owns a pool of hipEvents; while `model.profiler` is set, every forward goes through
-`pope_vit_forward_profiled_f32`, which records one event before each kernel launch on the launch
-stream.  After a synchronise, `summary()` turns the event pairs into per-kernel-kind durations.
+`pope_vit_forward_profiled_mask_f32`, which brackets the kernel launches of the selected kinds with events
+on the launch stream (all kinds by default; `kinds=("attention",)` times one kernel and leaves every other
+launch back to back as in the untimed path).  After a synchronise, `summary()` turns the event pairs into
+per-kernel-kind durations.
 """
 import ctypes as C
 from collections import defaultdict
@@ -14,10 +16,14 @@ KIND_NAMES = {0: "patch_embed_gemm", 1: "layernorm", 2: "gemm_qkv", 3: "attentio
               5: "gemm_fc1_gelu", 6: "gemm_fc2", 7: "tap_copy"}
 
 
+KIND_IDS = {v: k for k, v in KIND_NAMES.items()}
+
+
 class KernelProfiler:
-    def __init__(self, depth, max_forwards):
+    def __init__(self, depth, max_forwards, kinds=None):
         lib = _lib.lib()
-        self.per_forward = lib.pope_vit_launch_count(depth) + 1
+        self.mask = 0xFFFFFFFF if kinds is None else sum(1 << KIND_IDS[k] for k in kinds)
+        self.per_forward = 2 * lib.pope_vit_launch_count(depth) + 1  # worst case: start + close per launch
         self.max_forwards = max_forwards
         n = self.per_forward * max_forwards
         self.events = (C.c_void_p * n)()
@@ -48,6 +54,8 @@ class KernelProfiler:
         ms = C.c_float()
         for off, n in self.launches:
             for j in range(n):
+                if self.kinds[off + j] < 0:  # close-only event
+                    continue
                 check(lib.pope_event_elapsed_ms(self.events[off + j], self.events[off + j + 1], C.byref(ms)),
                       "pope_event_elapsed_ms")
                 acc[self.kinds[off + j]].append(ms.value)

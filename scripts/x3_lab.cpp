@@ -76,17 +76,39 @@ int main() {
             printf("   PLANES kernel: %.3f ms (%.1f TF-eq) maxerr %.2e\n", tp, gf / tp, e);
 #ifdef X3_STAMPS
             if (sh.K == 384) {
-                unsigned long long* dbg; hipMalloc(&dbg, 64 * 4 * 16 * 8); hipMemset(dbg, 0, 64 * 4 * 16 * 8);
+                const size_t nd = size_t(512) * 16 * 16;
+                unsigned long long* dbg; hipMalloc(&dbg, nd * 8); hipMemset(dbg, 0, nd * 8);
                 gp.posb = reinterpret_cast<const float*>(dbg);
-                pope_launch_gemm_nt_f16x3_planes(gp, 0); hipDeviceSynchronize();
-                std::vector<unsigned long long> hd(64 * 4 * 16);
-                hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
-                for (int b : {0, 9, 40}) for (int t = 1; t < 3; ++t) {
-                    auto* q = &hd[(b * 4 + t) * 16];
-                    printf("   block %2d tile %d: K-steps(0..9):", b, t);
-                    unsigned long long prev = q[0];
-                    for (int k = 1; k <= 10; ++k) { printf(" %llu", q[k] - prev); prev = q[k]; }
-                    printf(" | last two K-steps %llu | epilogue %llu | whole tile %llu\n", q[12] - q[10], q[13] - q[12], q[13] - q[0]);
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                hipEventRecord(e0); pope_launch_gemm_nt_f16x3_planes(gp, 0); hipEventRecord(e1); hipDeviceSynchronize();
+                float ems; hipEventElapsedTime(&ems, e0, e1);
+                std::vector<unsigned long long> hd(nd);
+                hipMemcpy(hd.data(), dbg, nd * 8, hipMemcpyDeviceToHost);
+                {
+                    unsigned long long t0 = ~0ull;
+                    for (int b = 0; b < 512; ++b) if (hd[(b * 16) * 16 + 14] && hd[(b * 16) * 16 + 14] < t0) t0 = hd[(b * 16) * 16 + 14];
+                    printf("   stamped launch: %.1f us by events; blocks [first K-step, last epilogue end] us after the earliest stamp:", ems * 1e3);
+                    for (int b = 0; b < 512; b += 37) {
+                        unsigned long long last_rt = 0; int nt = 0;
+                        for (int t = 0; t < 16; ++t) if (hd[(b * 16 + t) * 16 + 15]) { last_rt = hd[(b * 16 + t) * 16 + 15]; ++nt; }
+                        printf(" b%d[%.1f,%.1f;%dt]", b, (hd[(b * 16) * 16 + 14] - t0) / 100.0, (last_rt - t0) / 100.0, nt);
+                    }
+                    printf("\n");
+                }
+                for (int b : {0, 40}) {
+                    printf("   block %2d: per tile [K-loop | epilogue | gap to next tile]:", b);
+                    for (int t = 0; t < 15; ++t) {
+                        auto* q = &hd[(b * 16 + t) * 16];
+                        if (!q[13]) break;
+                        auto* qn = &hd[(b * 16 + t + 1) * 16];
+                        printf(" [%llu|%llu|%lld]", q[12] - q[0], q[13] - q[12], qn[0] ? (long long)(qn[0] - q[13]) : -1LL);
+                    }
+                    auto* q0 = &hd[(b * 16) * 16];
+                    unsigned long long last = 0, last_rt = 0;
+                    for (int t = 0; t < 16; ++t) if (hd[(b * 16 + t) * 16 + 13]) { last = hd[(b * 16 + t) * 16 + 13]; last_rt = hd[(b * 16 + t) * 16 + 15]; }
+                    const double us = (last_rt - q0[14]) / 100.0;   // s_memrealtime ticks at 100 MHz
+                    printf("  total first K-step..last epilogue %llu cycles in %.1f us -> shader clock %.3f GHz\n", last - q0[0], us,
+                           (last - q0[0]) / us / 1e3);
                 }
             }
 #endif

@@ -200,6 +200,26 @@ def test_linear_planes_kernel(dev, hip_lib, epi):
     _close(got, want, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(64 * 197 + 3, 1152, 384), (130, 100, 128), (9000, 384, 96), (300, 256, 64)])
+def test_linear_planes_ragged_shapes(dev, hip_lib, shape):
+    """Ragged M / N (rows and columns beyond the last tile are dropped by the buffer descriptors), odd numbers of
+    K-steps (the K-step stream runs in pairs; a trailing dummy item must not be stored), repeated launches."""
+    import ctypes as C
+    from pope_amd import _lib
+    M, N, K = shape
+    a, w, b = _rand(M, K, seed=71, scale=1.3), _rand(N, K, seed=72, scale=K ** -0.5), _rand(N, seed=73)
+    ap = _lib.to_planes(a, _lib.PLANES_ACT_SCALE).to(dev)
+    wp = _lib.to_planes(w, _lib.PLANES_W_SCALE).to(dev)
+    bd = b.to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    guard = torch.full((M + 2, N), 7.0, device=dev)      # rows M, M+1 must stay untouched
+    for _ in range(2):
+        assert hip_lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(guard), None, M, N, K, 0, None, None, st) == 0
+    assert bool((guard[M:] == 7.0).all())
+    _close(guard[:M].cpu(), F.linear(a.double(), w.double(), b.double()).float(), atol=1e-5, rtol=1e-5)
+
+
 def test_layernorm_planes_and_split(dev, hip_lib):
     import ctypes as C
     from pope_amd import _lib
