@@ -12,6 +12,7 @@
 // fp32 chain (tests/test_gpu_ops.py).  Range contract: |q|,|k|,|v| < 65504.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -264,6 +265,344 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_kernel(const float* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Software-pipelined variant.  Measured on gfx950 (scripts/overlap16_lab.hip): an f16 MFMA phase of one wave
+// does NOT overlap a VALU phase of another wave on the same SIMD (2 or 4 waves per SIMD, any priorities or start
+// skews: the phases add up), but VALU instructions placed BETWEEN the MFMAs of the same wave cost about 2 cycles
+// each instead of 4+ (t ~ 32 + 2 n cycles per MFMA with n VALU ops behind it).  So the only way to hide the
+// softmax is inside each wave's own instruction stream: here QK^T of tile t+1 is issued interleaved with the
+// max / exp / sum work of tile t, and P.V of tile t interleaved with the hi/lo splitting of P and of the K/V rows
+// of tile t+2 (every MFMA is followed by its slice of VALU work and a sched_barrier).  Three K/V stages in LDS:
+// tile t+2 is written (under the P.V MFMAs) into the stage nobody reads during iteration t, so an iteration has
+// ONE workgroup barrier and no store-only bubble (with two stages: barrier, store, barrier = 17 % of an iteration
+// with the matrix pipe idle).  One workgroup of 8 waves per CU (256 registers per wave at 2 waves per SIMD).
+#ifdef ATTN_STAMPS  // dev: per-iteration cycle stamps of block 300, wave 0 (scripts/attn_stamps.py)
+__device__ unsigned long long g_attn_dbg[32 * 8];
+#define ATTN_STAMP(t, slot)                                                                                     \
+    do {                                                                                                        \
+        if (blockIdx.x == 300 && tid == 0 && (t) < 32) g_attn_dbg[(t) * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define ATTN_STAMP(t, slot) do {} while (0)
+#endif
+constexpr int STAGE_H = 2 * (K_PLANE + V_PLANE);  // halves per K/V stage (Kh | Kl | Vh | Vl)
+constexpr size_t X3_ATTN_PIPE_BYTES = size_t(3) * STAGE_H * sizeof(_Float16);  // 129 024 B: three stages, see below
+static_assert(X3_ATTN_PIPE_BYTES >= X3_ATTN_EPI_BYTES, "epilogue staging fits the stages");
+
+template <bool OUT_PLANES>
+__global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                  int N, int heads) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* lds = reinterpret_cast<_Float16*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_qb = (N + QB - 1) / QB;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = logical / n_qb, head = bh % heads, b = bh / heads, q0 = (logical - bh * n_qb) * QB;
+    const int D = heads * HD, rs = 3 * D;
+    const float* base = qkv + size_t(b) * N * rs;
+    const int koff = D + head * HD;
+
+    constexpr float QSCALE = 0.125f * 1.44269504088896340736f;
+    f16x8 qh[4], ql[4];
+    {
+        const int qrow = q0 + wave * 32 + r;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if (qrow < N) {
+                const float* p = base + size_t(qrow) * rs + head * HD + 16 * kg + 8 * h;
+                v0 = *reinterpret_cast<const f32x4*>(p);
+                v1 = *reinterpret_cast<const f32x4*>(p + 4);
+            }
+            f16x4 h0, l0, h1, l1;
+            split4(v0 * QSCALE, h0, l0);
+            split4(v1 * QSCALE, h1, l1);
+            qh[kg] = cat(h0, h1);
+            ql[kg] = cat(l0, l1);
+        }
+    }
+
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, unsigned(N) * unsigned(rs) * 4u, 0x00020000);
+    constexpr int RPP = NT / 16, NP = KT / RPP;
+    const int srow = tid >> 4, scol = (tid & 15) * 4;
+    unsigned kvoff[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) kvoff[i] = (unsigned(srow + RPP * i) * unsigned(rs) + scol + koff) * 4u;
+    const unsigned tile_bytes = unsigned(KT) * unsigned(rs) * 4u, v_delta = unsigned(D) * 4u;
+    f32x4 rk[NP], rv[NP];
+    auto load_kv = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            rk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, kvoff[i], kt * tile_bytes, 0));
+            rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, kvoff[i] + v_delta, kt * tile_bytes, 0));
+        }
+    };
+    // K/V rows of the tile in flight, already split (done under the P.V MFMAs), and their LDS store
+    f16x4 skh[NP], skl[NP], svh[NP], svl[NP];
+    auto split_kv = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            split4(rk[i], skh[i], skl[i]);
+            split4(rv[i], svh[i], svl[i]);
+        }
+    };
+    auto write_k_row = [&](int st, int i) {
+        _Float16* S = lds + st * STAGE_H;
+        *reinterpret_cast<f16x4*>(S + (srow + RPP * i) * KST + scol) = skh[i];
+        *reinterpret_cast<f16x4*>(S + K_PLANE + (srow + RPP * i) * KST + scol) = skl[i];
+    };
+    auto write_v_row = [&](int st, int i) {
+        _Float16* S = lds + st * STAGE_H;
+        *reinterpret_cast<f16x4*>(S + 2 * K_PLANE + (srow + RPP * i) * VST + scol) = svh[i];
+        *reinterpret_cast<f16x4*>(S + 2 * K_PLANE + V_PLANE + (srow + RPP * i) * VST + scol) = svl[i];
+    };
+    auto write_kv = [&](int st) {
+        _Float16* S = lds + st * STAGE_H;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            *reinterpret_cast<f16x4*>(S + (srow + RPP * i) * KST + scol) = skh[i];
+            *reinterpret_cast<f16x4*>(S + K_PLANE + (srow + RPP * i) * KST + scol) = skl[i];
+            *reinterpret_cast<f16x4*>(S + 2 * K_PLANE + (srow + RPP * i) * VST + scol) = svh[i];
+            *reinterpret_cast<f16x4*>(S + 2 * K_PLANE + V_PLANE + (srow + RPP * i) * VST + scol) = svl[i];
+        }
+    };
+
+    const int tr_off = (4 * h + ((lane & 15) >> 2)) * VST + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto vfrag = [&](const _Float16* plane, int u, int s, int dt) {
+        const _Float16* p = plane + tr_off + (32 * u + 16 * s) * VST + 32 * dt;
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+        const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 8 * VST));
+        return cat(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, c));
+    };
+
+    f32x16 o0, o1, c0, c1, n0, n1;  // output accumulators; scores / probabilities of tile t; scores of tile t+1
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m_run = -INFINITY;
+    f32x2 l_run = {0.f, 0.f};
+
+    struct KFrag { f16x8 k0h, k0l, k1h, k1l; };
+    auto read_kfrag = [&](int st, int kg, KFrag& f) {
+        const _Float16* kb_h = lds + st * STAGE_H + r * KST + 8 * h + 16 * kg;
+        f.k0h = *reinterpret_cast<const f16x8*>(kb_h);
+        f.k0l = *reinterpret_cast<const f16x8*>(kb_h + K_PLANE);
+        f.k1h = *reinterpret_cast<const f16x8*>(kb_h + 32 * KST);
+        f.k1l = *reinterpret_cast<const f16x8*>(kb_h + K_PLANE + 32 * KST);
+    };
+    auto qk_step = [&](int kg, int j, const KFrag& f, f32x16& d0, f32x16& d1) {  // MFMA j (0..5) of d step kg
+        if (j == 0) d0 = mfma_f16(f.k0l, qh[kg], d0);
+        if (j == 1) d1 = mfma_f16(f.k1l, qh[kg], d1);
+        if (j == 2) d0 = mfma_f16(f.k0h, ql[kg], d0);
+        if (j == 3) d1 = mfma_f16(f.k1h, ql[kg], d1);
+        if (j == 4) d0 = mfma_f16(f.k0h, qh[kg], d0);
+        if (j == 5) d1 = mfma_f16(f.k1h, qh[kg], d1);
+    };
+    auto mask_tail = [&](int kt, f32x16& d0, f32x16& d1) {  // padded keys of the last tile
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = kt * KT + mfma32_row(i, h);
+            if (key >= N) d0[i] = -INFINITY;
+            if (key + 32 >= N) d1[i] = -INFINITY;
+        }
+    };
+    // Slice `slot` (0..23) of the online softmax of (c0, c1), in place (log2 domain; p' = 2^(s - m + 10)).  o and l
+    // are rescaled unconditionally (alpha == 1 exactly when the row maximum did not move): no branch in the phase.
+    float sm_mt = 0.f, sm_alpha = 0.f, sm_shift = 0.f;
+    f32x2 sm_ls = {0.f, 0.f};
+    auto softmax_slice = [&](int slot) {
+        if (slot == 0) {
+            sm_mt = vmax3(c0[0], c1[0], c0[1]);
+#pragma unroll
+            for (int i = 1; i < 8; ++i) sm_mt = vmax3(sm_mt, c1[i], c0[i + 1]);
+        } else if (slot == 1) {
+#pragma unroll
+            for (int i = 8; i < 15; ++i) sm_mt = vmax3(sm_mt, c1[i], c0[i + 1]);
+            sm_mt = vmax3(sm_mt, c1[15], c1[15]);
+        } else if (slot == 2) {
+            sm_mt = __builtin_fmaxf(sm_mt, __shfl_xor(sm_mt, 32));
+            const float m_new = __builtin_fmaxf(m_run, sm_mt);
+            sm_alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            sm_shift = m_new - 10.0f;
+            l_run = l_run * sm_alpha;
+            sm_ls = f32x2{0.f, 0.f};
+        } else if (slot < 7) {  // 3..6: a quarter of the output accumulators each
+            const int q = slot - 3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (q < 2) o0[8 * q + e] *= sm_alpha;
+                else o1[8 * (q - 2) + e] *= sm_alpha;
+            }
+        } else if (slot < 23) {  // 7..22: two probabilities of each sub-tile
+            const int i = slot - 7;
+            c0[i] = __builtin_amdgcn_exp2f(c0[i] - sm_shift);
+            c1[i] = __builtin_amdgcn_exp2f(c1[i] - sm_shift);
+            sm_ls += f32x2{c0[i], c1[i]};
+        } else {
+            l_run += sm_ls;
+        }
+    };
+    // ---- phase 1: S^T(tile in stage st_next) -> (n0, n1), each MFMA followed by a slice of the softmax of (c0, c1)
+    auto phase1 = [&](int st_next) {
+        KFrag kf[2];
+        read_kfrag(st_next, 0, kf[0]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { n0[i] = 0.f; n1[i] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            const int kg = i / 6, j = i % 6;
+            if (j == 0 && kg < 3) read_kfrag(st_next, kg + 1, kf[(kg + 1) & 1]);
+            qk_step(kg, j, kf[kg & 1], n0, n1);
+            softmax_slice(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto softmax_only = [&]() {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) softmax_slice(i);
+    };
+    // ---- phase 2: O^T += V^T(stage st) . P^T with P = (c0, c1); the hi/lo split of the next 16 keys' probabilities
+    // (and, SPLIT_KV, of one K/V row of tile t+2 per group) sits behind the MFMAs of the current 16 keys
+    auto split_group = [&](int g, int half, f16x4& hi, f16x4& lo) {
+        const int u = g >> 1, s2 = g & 1;
+        f32x4 pv4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv4[e] = (u ? c1 : c0)[8 * s2 + 4 * half + e];
+        split4(pv4, hi, lo);
+    };
+    auto phase2 = [&](int st, int st_write, auto split_tag) {
+        constexpr bool SPLIT_KV = decltype(split_tag)::value;
+        const _Float16* Vh = lds + st * STAGE_H + 2 * K_PLANE;
+        const _Float16* Vl = Vh + V_PLANE;
+        f16x4 h0[2], l0[2], h1[2], l1[2];
+        f16x8 vf[2][4];
+        split_group(0, 0, h0[0], l0[0]);
+        split_group(0, 1, h1[0], l1[0]);
+        vf[0][0] = vfrag(Vh, 0, 0, 0); vf[0][1] = vfrag(Vl, 0, 0, 0);
+        vf[0][2] = vfrag(Vh, 0, 0, 1); vf[0][3] = vfrag(Vl, 0, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            const int g = i / 6, j = i % 6, cur = g & 1, nxt = cur ^ 1;
+            if (j == 0 && g < 3) {
+                const int u = (g + 1) >> 1, s2 = (g + 1) & 1;
+                vf[nxt][0] = vfrag(Vh, u, s2, 0); vf[nxt][1] = vfrag(Vl, u, s2, 0);
+                vf[nxt][2] = vfrag(Vh, u, s2, 1); vf[nxt][3] = vfrag(Vl, u, s2, 1);
+            }
+            const f16x8 ph = cat(h0[cur], h1[cur]), pl = cat(l0[cur], l1[cur]);
+            if (j == 0) o0 = mfma_f16(vf[cur][1], ph, o0);
+            if (j == 1) o1 = mfma_f16(vf[cur][3], ph, o1);
+            if (j == 2) o0 = mfma_f16(vf[cur][0], pl, o0);
+            if (j == 3) o1 = mfma_f16(vf[cur][2], pl, o1);
+            if (j == 4) o0 = mfma_f16(vf[cur][0], ph, o0);
+            if (j == 5) o1 = mfma_f16(vf[cur][2], ph, o1);
+            if (g < 3) {
+                if (j == 1) split_group(g + 1, 0, h0[nxt], l0[nxt]);
+                if (j == 3) split_group(g + 1, 1, h1[nxt], l1[nxt]);
+            }
+            if (SPLIT_KV && j == 5) {  // one of the four K/V rows in flight (tile t+2) per 16-key group: split + store
+                const int i2 = g >> 1;
+                if (g & 1) { split4(rv[i2], svh[i2], svl[i2]); write_v_row(st_write, i2); }
+                else { split4(rk[i2], skh[i2], skl[i2]); write_k_row(st_write, i2); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int nkt = (N + KT - 1) / KT;
+    // prologue: tile 0 -> stage 0, S^T(0); tile 1 -> stage 1; loads of tile 2 in flight
+    load_kv(0);
+    split_kv();
+    write_kv(0);
+    if (nkt > 1) load_kv(1);
+    __syncthreads();
+    {
+        KFrag kf;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; }
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            read_kfrag(0, kg, kf);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) qk_step(kg, j, kf, c0, c1);
+        }
+    }
+    if (nkt == 1) mask_tail(0, c0, c1);
+    if (nkt > 1) {
+        split_kv();
+        write_kv(1);
+        if (nkt > 2) load_kv(2);
+    }
+    __syncthreads();
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c0), "+v"(c1));  // XDL write -> asm VALU read (vmax3) wait states
+
+    // stage of tile t = t % 3
+    int st_cur = 0, st_next = 1, st_write = 2, t = 0;
+    auto rotate = [&]() { const int x = st_cur; st_cur = st_next; st_next = st_write; st_write = x; };
+    for (; t + 2 < nkt; ++t) {  // steady state: tiles t+1 and t+2 exist
+        ATTN_STAMP(t, 0);
+        phase1(st_next);
+        ATTN_STAMP(t, 1);
+        phase2(st_cur, st_write, std::true_type{});  // also moves tile t+2 from registers into stage st_write
+        if (t + 3 < nkt) load_kv(t + 3);
+        ATTN_STAMP(t, 2);
+        __syncthreads();  // tile t+2 is published; every wave is done with stage st_cur
+        ATTN_STAMP(t, 3);
+        c0 = n0;
+        c1 = n1;
+        rotate();
+    }
+    if (t + 1 < nkt) {  // second-to-last tile: S^T of the last tile needs the key mask
+        phase1(st_next);
+        mask_tail(t + 1, n0, n1);
+        asm volatile("" : "+v"(n0), "+v"(n1));
+        phase2(st_cur, st_write, std::false_type{});
+        c0 = n0;
+        c1 = n1;
+        rotate();
+        ++t;
+    }
+    softmax_only();  // last tile
+    phase2(st_cur, st_write, std::false_type{});
+    __syncthreads();  // the stages are free: reuse them for the O^T transpose
+
+    // Normalise (the 2^10 of p' cancels), transpose O^T through LDS, store whole 256-B head rows.
+    const float l_half = l_run[0] + l_run[1];
+    const float inv = 1.0f / (l_half + __shfl_xor(l_half, 32));
+    float* Os = smem + (wave * 32) * OST;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = o0[4 * g4 + e] * inv; c[e] = o1[4 * g4 + e] * inv; }
+        *reinterpret_cast<f32x4*>(&Os[r * OST + 8 * g4 + 4 * h]) = a;
+        *reinterpret_cast<f32x4*>(&Os[r * OST + 32 + 8 * g4 + 4 * h]) = c;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int lr = (lane >> 4) + 4 * i, c4 = (lane & 15) * 4;
+        const int qrow = q0 + wave * 32 + lr;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&Os[lr * OST + c4]);
+        if (qrow < N) {
+            if constexpr (OUT_PLANES) {
+                f16x4 hi, lo;
+                split4(v * 8.0f, hi, lo);  // K_PLANES_ACT_SCALE
+                const int col = head * HD + c4;
+                _Float16* o = reinterpret_cast<_Float16*>(out) + (size_t(b) * N + qrow) * 2 * D + (col >> 5) * 64 + (col & 31);
+                *reinterpret_cast<f16x4*>(o) = hi;
+                *reinterpret_cast<f16x4*>(o + 32) = lo;
+            } else {
+                *reinterpret_cast<f32x4*>(out + (size_t(b) * N + qrow) * D + head * HD + c4) = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static_assert(K_PLANES_ACT_SCALE == 8.0f, "attention planes epilogue scale");
@@ -274,6 +613,18 @@ static int launch_attn_x3(const float* qkv, float* out, int B, int N, int heads,
     if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return POPE_ERR_ARG;
     if (size_t(N) * 3 * heads * HD * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
     const dim3 grid(unsigned((N + QB - 1) / QB) * heads * B);
+    static const bool pipe = !getenv("POPE_ATTN_NO_PIPE");  // dev switch: the un-pipelined kernel, for A/B runs
+    if (pipe) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_pipe_kernel<OUT_PLANES>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(X3_ATTN_PIPE_BYTES)) != hipSuccess)
+                return POPE_ERR_LAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_f16x3_pipe_kernel<OUT_PLANES>, grid, dim3(NT), X3_ATTN_PIPE_BYTES, stream, qkv, out, N, heads);
+        return pope_check_launch();
+    }
     constexpr size_t lds = X3_ATTN_STAGE_BYTES > X3_ATTN_EPI_BYTES ? X3_ATTN_STAGE_BYTES : X3_ATTN_EPI_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
@@ -285,6 +636,12 @@ static int launch_attn_x3(const float* qkv, float* out, int B, int N, int heads,
     hipLaunchKernelGGL(attn_f16x3_kernel<OUT_PLANES>, grid, dim3(NT), lds, stream, qkv, out, N, heads);
     return pope_check_launch();
 }
+
+#ifdef ATTN_STAMPS
+extern "C" int pope_lab_attn_stamps(unsigned long long* host256) {
+    return hipMemcpyFromSymbol(host256, HIP_SYMBOL(g_attn_dbg), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream) {
     return launch_attn_x3<false>(qkv, out, B, N, heads, stream);
