@@ -236,9 +236,19 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     // Tile order: static round robin over the XCD-remapped workgroup id.  (The two workgroups of a CU do not
     // progress evenly — the first-dispatched one runs ~1.4x faster and the other finishes its share alone — but
     // neither an atomic tile queue nor an unequal static split shortened the launch: DESIGN.md §4, finding 4.)
-    const int stride = gridDim.x;
-    const int first = xcd_remap(blockIdx.x, gridDim.x);
+    // Full rounds: tile = round * grid + XCD-remapped id.  The last, partial round is dealt by raw blockIdx instead:
+    // its tiles then go to workgroups 0, 1, 2, ... = one per CU across all XCDs (each runs alone on its CU, at the
+    // solo rate), instead of filling both workgroup slots of the first XCDs' CUs while the other XCDs idle.
+    const int grid = gridDim.x, full_rounds = n_tiles / grid;
+    const int remapped = xcd_remap(blockIdx.x, grid);
+    auto tile_of = [&](int ord) -> int {
+        if (ord < full_rounds) return ord * grid + remapped;
+        const int t = full_rounds * grid + int(blockIdx.x);
+        return (ord == full_rounds && t < n_tiles) ? t : n_tiles;
+    };
+    const int first = tile_of(0);
     if (first >= n_tiles) return;
+    int ld_ord = 0, ord = 0;
     int ld_tile = first, ld_kt = 0;  // next stream item to load
     auto load_next = [&](u32x4 (&st)[8]) {
         {   // branch-free (an item must be ONE basic block for the interleave below): past the end of the
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
                 st[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, ld_kt * 128, 0);
                 st[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, ld_kt * 128, 0);
             }
-            if (++ld_kt == nk) { ld_kt = 0; ld_tile += stride; }
+            if (++ld_kt == nk) { ld_kt = 0; ld_tile = tile_of(++ld_ord); }
         }
     };
     auto write_stage = [&](int s, const u32x4 (&st)[8]) {
@@ -395,6 +405,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     __syncthreads();
     zero_acc();
     int tile = first, kt = 0;
+
     // one stream item; `nx` holds item s+1 (to be published), then is refilled with item s+3
     // Order inside an item: the fragment reads of this item are issued FIRST, their LDS latency runs
     // under the ds_writes / buffer loads of the staging work; the second half's fragments are read
@@ -446,7 +457,8 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
 #endif
             zero_acc();
             kt = 0;
-            tile += stride;
+            tile = tile_of(++ord);
+
         }
     };
     for (int s = 0; tile < n_tiles; s += 2) {
