@@ -237,7 +237,7 @@ def main():
             result["kernels"] = tab
             result["kernels_note"] = "every launch of the last warm-up step bracketed by HIP events"
             result["vit_kernel_ms_per_step"] = round(sum(t["ms_per_step"] for t in tab), 3)
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N = 1 only (the other ranks would idle)
         result["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
     if world > 1:
         dist.barrier()
