@@ -86,6 +86,9 @@ int pope_patch_embed_f32(const float* img, const float* proj_w, const float* pos
 int pope_attention_f32(const float* qkv, float* out, int B, int N, int heads, void* stream);
 /* Same with an explicit POPE_PREC_* (pope_attention_f32 == POPE_PREC_F32_MFMA). */
 int pope_attention_prec_f32(const float* qkv, float* out, int B, int N, int heads, int precision, void* stream);
+/* f16x3 attention on planes (layout and scale: POPE_PLANES_* below): qkv_planes [B*N, 3*heads*64] as written by
+ * pope_linear_planes_f32(..., c_planes), out_planes [B*N, heads*64] as read by the proj GEMM.  heads*64 % 32 == 0. */
+int pope_attention_planes_f32(const void* qkv_planes, void* out_planes, int B, int N, int heads, void* stream);
 
 /* F.cosine_similarity(ref[1,D], fea[P,D], dim=1, eps) — eval_linemod_json.py:94. */
 int pope_cls_cosine_f32(const float* ref, const float* fea, int P, int D, float eps, float* scores,

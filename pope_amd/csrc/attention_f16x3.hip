@@ -290,7 +290,10 @@ constexpr int STAGE_H = 2 * (K_PLANE + V_PLANE);  // halves per K/V stage (Kh | 
 constexpr size_t X3_ATTN_PIPE_BYTES = size_t(3) * STAGE_H * sizeof(_Float16);  // 129 024 B: three stages, see below
 static_assert(X3_ATTN_PIPE_BYTES >= X3_ATTN_EPI_BYTES, "epilogue staging fits the stages");
 
-template <bool OUT_PLANES>
+// IN_PLANES: qkv is the planes tensor the QKV GEMM's epilogue writes (pope_hip.h layout, scale 8): K/V rows go to
+// LDS as they are (no per-tile hi/lo split: 48 VALU instructions, 8 LDS stores and a wait on loads issued one
+// iteration earlier per wave and tile -> 16-byte copies from registers loaded TWO iterations earlier).
+template <bool OUT_PLANES, bool IN_PLANES>
 __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                   int N, int heads) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -305,7 +308,8 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     const float* base = qkv + size_t(b) * N * rs;
     const int koff = D + head * HD;
 
-    constexpr float QSCALE = 0.125f * 1.44269504088896340736f;
+    // planes carry x8 (K_PLANES_ACT_SCALE): the K factor is folded into Q here, the V factor into the final 1/l
+    constexpr float QSCALE = 0.125f * 1.44269504088896340736f * (IN_PLANES ? 0.125f * 0.125f : 1.0f);
     f16x8 qh[4], ql[4];
     {
         const int qrow = q0 + wave * 32 + r;
@@ -313,9 +317,20 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         for (int kg = 0; kg < 4; ++kg) {
             f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
             if (qrow < N) {
-                const float* p = base + size_t(qrow) * rs + head * HD + 16 * kg + 8 * h;
-                v0 = *reinterpret_cast<const f32x4*>(p);
-                v1 = *reinterpret_cast<const f32x4*>(p + 4);
+                if constexpr (IN_PLANES) {  // 8 hi + 8 lo halves of chunk head*2 + kg/2 -> (hi + lo), still x8
+                    const _Float16* p = reinterpret_cast<const _Float16*>(base) + size_t(qrow) * 2 * rs +
+                                        (head * 2 + (kg >> 1)) * 64 + 16 * (kg & 1) + 8 * h;
+                    const f16x8 ph = *reinterpret_cast<const f16x8*>(p), pl = *reinterpret_cast<const f16x8*>(p + 32);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v0[e] = float(ph[e]) + float(pl[e]);
+                        v1[e] = float(ph[4 + e]) + float(pl[4 + e]);
+                    }
+                } else {
+                    const float* p = base + size_t(qrow) * rs + head * HD + 16 * kg + 8 * h;
+                    v0 = *reinterpret_cast<const f32x4*>(p);
+                    v1 = *reinterpret_cast<const f32x4*>(p + 4);
+                }
             }
             f16x4 h0, l0, h1, l1;
             split4(v0 * QSCALE, h0, l0);
@@ -369,6 +384,27 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
             *reinterpret_cast<f16x4*>(S + 2 * K_PLANE + (srow + RPP * i) * VST + scol) = svh[i];
             *reinterpret_cast<f16x4*>(S + 2 * K_PLANE + V_PLANE + (srow + RPP * i) * VST + scol) = svl[i];
         }
+    };
+
+    // IN_PLANES staging: thread -> (key = tid >> 3, 16-byte piece p = tid & 7 of a 128-byte chunk [32 hi | 32 lo]);
+    // four chunks per key (K d 0..31, K d 32..63, V d 0..31, V d 32..63), two register sets = two tiles in flight.
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 pa[4] = {}, pb[4] = {};
+    const int pkey = tid >> 3, pp = tid & 7;
+    const unsigned pl_off = unsigned(pkey) * unsigned(rs) * 4u + unsigned((D >> 5) + head * 2) * 128u + unsigned(pp) * 16u;
+    const unsigned pl_vdelta = unsigned(D >> 5) * 128u;
+    auto load_planes = [&](int kt, u32x4 (&st)[4]) {
+        // never address a tile past the last one: the descriptor's range check subtracts the scalar tile offset
+        // from the extent, which must not go negative (the stale registers are then stored to a stage nobody reads)
+        if (kt * KT >= N) return;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            st[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, pl_off + (c >> 1) * pl_vdelta + (c & 1) * 128u, kt * tile_bytes, 0);
+    };
+    auto write_chunk = [&](int st, int c, const u32x4 (&regs)[4]) {  // c = 0, 1: K; 2, 3: V
+        _Float16* S = lds + st * STAGE_H + (c < 2 ? 0 : 2 * K_PLANE) + (pp >> 2) * (c < 2 ? K_PLANE : V_PLANE) +
+                      pkey * (c < 2 ? KST : VST) + (c & 1) * 32 + (pp & 3) * 8;
+        *reinterpret_cast<u32x4*>(S) = regs[c];
     };
 
     const int tr_off = (4 * h + ((lane & 15) >> 2)) * VST + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -474,7 +510,7 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         for (int e = 0; e < 4; ++e) pv4[e] = (u ? c1 : c0)[8 * s2 + 4 * half + e];
         split4(pv4, hi, lo);
     };
-    auto phase2 = [&](int st, int st_write, auto split_tag) {
+    auto phase2 = [&](int st, int st_write, auto split_tag, const u32x4 (&pregs)[4]) {
         constexpr bool SPLIT_KV = decltype(split_tag)::value;
         const _Float16* Vh = lds + st * STAGE_H + 2 * K_PLANE;
         const _Float16* Vl = Vh + V_PLANE;
@@ -504,10 +540,14 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
                 if (j == 1) split_group(g + 1, 0, h0[nxt], l0[nxt]);
                 if (j == 3) split_group(g + 1, 1, h1[nxt], l1[nxt]);
             }
-            if (SPLIT_KV && j == 5) {  // one of the four K/V rows in flight (tile t+2) per 16-key group: split + store
-                const int i2 = g >> 1;
-                if (g & 1) { split4(rv[i2], svh[i2], svl[i2]); write_v_row(st_write, i2); }
-                else { split4(rk[i2], skh[i2], skl[i2]); write_k_row(st_write, i2); }
+            if (SPLIT_KV && j == 5) {  // a quarter of tile t+2's staging per 16-key group
+                if constexpr (IN_PLANES) {
+                    write_chunk(st_write, g, pregs);
+                } else {
+                    const int i2 = g >> 1;
+                    if (g & 1) { split4(rv[i2], svh[i2], svl[i2]); write_v_row(st_write, i2); }
+                    else { split4(rk[i2], skh[i2], skl[i2]); write_k_row(st_write, i2); }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -515,10 +555,18 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
 
     const int nkt = (N + KT - 1) / KT;
     // prologue: tile 0 -> stage 0, S^T(0); tile 1 -> stage 1; loads of tile 2 in flight
-    load_kv(0);
-    split_kv();
-    write_kv(0);
-    if (nkt > 1) load_kv(1);
+    if constexpr (IN_PLANES) {
+        load_planes(0, pa);
+        load_planes(1, pb);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) write_chunk(0, c, pa);
+        load_planes(2, pa);
+    } else {
+        load_kv(0);
+        split_kv();
+        write_kv(0);
+        if (nkt > 1) load_kv(1);
+    }
     __syncthreads();
     {
         KFrag kf;
@@ -532,7 +580,11 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         }
     }
     if (nkt == 1) mask_tail(0, c0, c1);
-    if (nkt > 1) {
+    if constexpr (IN_PLANES) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) write_chunk(1, c, pb);
+        load_planes(3, pb);  // now: pa = tile 2, pb = tile 3
+    } else if (nkt > 1) {
         split_kv();
         write_kv(1);
         if (nkt > 2) load_kv(2);
@@ -543,36 +595,43 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     // stage of tile t = t % 3
     int st_cur = 0, st_next = 1, st_write = 2, t = 0;
     auto rotate = [&]() { const int x = st_cur; st_cur = st_next; st_next = st_write; st_write = x; };
-    for (; t + 2 < nkt; ++t) {  // steady state: tiles t+1 and t+2 exist
+    // one steady-state iteration (tiles t+1 and t+2 exist); `regs` holds tile t+2 and is refilled with tile t+4
+    auto steady = [&](u32x4 (&regs)[4]) {
         ATTN_STAMP(t, 0);
         phase1(st_next);
         ATTN_STAMP(t, 1);
-        phase2(st_cur, st_write, std::true_type{});  // also moves tile t+2 from registers into stage st_write
-        if (t + 3 < nkt) load_kv(t + 3);
+        phase2(st_cur, st_write, std::true_type{}, regs);  // also moves tile t+2 from registers into stage st_write
+        if constexpr (IN_PLANES) load_planes(t + 4, regs);
+        else if (t + 3 < nkt) load_kv(t + 3);
         ATTN_STAMP(t, 2);
         __syncthreads();  // tile t+2 is published; every wave is done with stage st_cur
         ATTN_STAMP(t, 3);
         c0 = n0;
         c1 = n1;
         rotate();
+        ++t;
+    };
+    while (t + 2 < nkt) {
+        steady(pa);
+        if (t + 2 < nkt) steady(pb);
     }
     if (t + 1 < nkt) {  // second-to-last tile: S^T of the last tile needs the key mask
         phase1(st_next);
         mask_tail(t + 1, n0, n1);
         asm volatile("" : "+v"(n0), "+v"(n1));
-        phase2(st_cur, st_write, std::false_type{});
+        phase2(st_cur, st_write, std::false_type{}, pa);
         c0 = n0;
         c1 = n1;
         rotate();
         ++t;
     }
     softmax_only();  // last tile
-    phase2(st_cur, st_write, std::false_type{});
+    phase2(st_cur, st_write, std::false_type{}, pa);
     __syncthreads();  // the stages are free: reuse them for the O^T transpose
 
     // Normalise (the 2^10 of p' cancels), transpose O^T through LDS, store whole 256-B head rows.
     const float l_half = l_run[0] + l_run[1];
-    const float inv = 1.0f / (l_half + __shfl_xor(l_half, 32));
+    const float inv = (IN_PLANES ? 0.125f : 1.0f) / (l_half + __shfl_xor(l_half, 32));  // V planes carry x8
     float* Os = smem + (wave * 32) * OST;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
@@ -617,12 +676,12 @@ static int launch_attn_x3(const float* qkv, float* out, int B, int N, int heads,
     if (pipe) {
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_pipe_kernel<OUT_PLANES>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_pipe_kernel<OUT_PLANES, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(X3_ATTN_PIPE_BYTES)) != hipSuccess)
                 return POPE_ERR_LAUNCH;
             attr_set = true;
         }
-        hipLaunchKernelGGL(attn_f16x3_pipe_kernel<OUT_PLANES>, grid, dim3(NT), X3_ATTN_PIPE_BYTES, stream, qkv, out, N, heads);
+        hipLaunchKernelGGL((attn_f16x3_pipe_kernel<OUT_PLANES, false>), grid, dim3(NT), X3_ATTN_PIPE_BYTES, stream, qkv, out, N, heads);
         return pope_check_launch();
     }
     constexpr size_t lds = X3_ATTN_STAGE_BYTES > X3_ATTN_EPI_BYTES ? X3_ATTN_STAGE_BYTES : X3_ATTN_EPI_BYTES;
@@ -646,6 +705,23 @@ extern "C" int pope_lab_attn_stamps(unsigned long long* host256) {
 int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream) {
     return launch_attn_x3<false>(qkv, out, B, N, heads, stream);
 }
+int pope_launch_attention_f16x3_planes_io(const void* qkv_planes, void* out_planes, int B, int N, int heads, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || heads <= 0 || ((heads * HD) & 31) || size_t(B) * heads * ((N + QB - 1) / QB) > 0x7fffffffull) return POPE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(qkv_planes) & 15) || (reinterpret_cast<uintptr_t>(out_planes) & 15)) return POPE_ERR_ARG;
+    if (size_t(N) * 3 * heads * HD * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
+    const dim3 grid(unsigned((N + QB - 1) / QB) * heads * B);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_pipe_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(X3_ATTN_PIPE_BYTES)) != hipSuccess)
+            return POPE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_f16x3_pipe_kernel<true, true>), grid, dim3(NT), X3_ATTN_PIPE_BYTES, stream,
+                       static_cast<const float*>(qkv_planes), static_cast<float*>(out_planes), N, heads);
+    return pope_check_launch();
+}
+
 int pope_launch_attention_f16x3_planes(const float* qkv, void* out_planes, int B, int N, int heads, hipStream_t stream) {
     if ((heads * HD) & 31) return POPE_ERR_ARG;
     return launch_attn_x3<true>(qkv, static_cast<float*>(out_planes), B, N, heads, stream);

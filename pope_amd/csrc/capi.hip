@@ -133,6 +133,11 @@ int pope_patch_embed_f32(const float* img, const float* proj_w, const float* pos
     return pope_launch_gemm_nt_f32(g, static_cast<hipStream_t>(stream));
 }
 
+int pope_attention_planes_f32(const void* qkv_planes, void* out_planes, int B, int N, int heads, void* stream) {
+    if (!qkv_planes || !out_planes) return POPE_ERR_ARG;
+    return pope_launch_attention_f16x3_planes_io(qkv_planes, out_planes, B, N, heads, static_cast<hipStream_t>(stream));
+}
+
 int pope_attention_f32(const float* qkv, float* out, int B, int N, int heads, void* stream) {
     return pope_attention_prec_f32(qkv, out, B, N, heads, POPE_PREC_F32_MFMA, stream);
 }
@@ -200,7 +205,10 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
             if ((rc = pope_launch_layernorm_f32(x, dim, k.norm1_w, k.norm1_b, xn, dim, rows, dim, eps, stream))) return rc;
         }
         POPE_MARK(POPE_K_GEMM_QKV);
-        if (planes) {
+        if (proj_planes) {  // q, k, v stay planes from the QKV epilogue to the attention kernel's LDS
+            if ((rc = pope_linear_planes_f32(xn_pl, k.qkv_wp, k.qkv_b, nullptr, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr,
+                                             stream))) return rc;
+        } else if (planes) {
             if ((rc = pope_linear_planes_f32(xn_pl, k.qkv_wp, k.qkv_b, qkv, nullptr, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr,
                                              stream))) return rc;
         } else {
@@ -208,7 +216,7 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
         }
         POPE_MARK(POPE_K_ATTENTION);
         if (proj_planes) {
-            if ((rc = pope_launch_attention_f16x3_planes(qkv, att, B, ntok, w->heads, stream))) return rc;
+            if ((rc = pope_launch_attention_f16x3_planes_io(qkv, att, B, ntok, w->heads, stream))) return rc;
         } else {
             if ((rc = pope_attention_prec_f32(qkv, att, B, ntok, w->heads, prec, stream))) return rc;
         }

@@ -59,6 +59,8 @@ int pope_launch_attention_f32(const float* qkv, float* out, int B, int N, int he
 int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream);
 // same, output as activation planes [B*N, heads*64] for the f16x3 proj GEMM
 int pope_launch_attention_f16x3_planes(const float* qkv, void* out_planes, int B, int N, int heads, hipStream_t stream);
+// qkv given as planes (the QKV GEMM epilogue's output), output planes: the whole-model f16x3 dataflow
+int pope_launch_attention_f16x3_planes_io(const void* qkv_planes, void* out_planes, int B, int N, int heads, hipStream_t stream);
 
 struct MatchParams {
     const float* feat0;  // [n, L, C]

@@ -158,6 +158,34 @@ def test_attention_online_softmax_rescale_branch(dev, prec):
     _close(got, want, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,N,heads,spike", [(2, 257, 6, False), (1, 1531, 6, False), (3, 64, 2, False), (1, 130, 6, False),
+                                             (1, 300, 6, True)])
+def test_attention_planes_in_planes_out(dev, hip_lib, B, N, heads, spike):
+    """The whole-model f16x3 dataflow: q, k, v as hi/lo planes (what the QKV GEMM epilogue writes) -> attention ->
+    output planes (what the proj GEMM reads), through the C ABI, against fp64 on the values the planes represent.
+    Covers one / two / many key tiles, a ragged last tile, and a late spike that forces a large rescale."""
+    import ctypes as C
+    from pope_amd import _lib
+    D = heads * 64
+    qkv = _rand(B, N, 3 * D, seed=40 + N, scale=0.5 if spike else 1.5)
+    if spike:
+        t = qkv.view(B, N, 3, heads, 64)
+        t[0, 250, 1] = t[0, 10, 0] * 40.0
+        t[0, 290, 1] = t[0, 70, 0] * -40.0
+    planes = _lib.to_planes(qkv.reshape(B * N, 3 * D), _lib.PLANES_ACT_SCALE)
+    seen = _lib.from_planes(planes, _lib.PLANES_ACT_SCALE).double().reshape(B, N, 3 * D)   # what the kernel sees
+    q, k, v = seen.reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    want = (((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B * N, D)
+    pin = planes.to(dev)
+    pout = torch.zeros(B * N, D // 32, 2, 32, dtype=torch.float16, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert hip_lib.pope_attention_planes_f32(C.c_void_p(pin.data_ptr()), C.c_void_p(pout.data_ptr()), B, N, heads, st) == 0
+    got = _lib.from_planes(pout.cpu(), _lib.PLANES_ACT_SCALE).double()
+    err = float(((got - want).abs() / (1.0 + want.abs())).max())
+    print(f"planes attention B={B} N={N}: max scaled |err| vs fp64 = {err:.2e}")
+    assert err < 2e-5, err
+
+
 def test_cls_cosine_and_top3(dev, golden_dir):
     import os
     from pope_amd import ops
