@@ -12,6 +12,7 @@
 // element that matters stays in the f16 normal range: the representation is relative (2^-22) for
 // |a| >= 2^-6 and |w| >= 2^-11 and absolute (2^-28 resp. 2^-33) below — far under the fp32 chain's
 // own rounding for O(1) activations.  Range contract: |a| < 8188, |w| < 255 (f16 max / scale).
+#include <cstdlib>
 #include "gemm_core.h"
 #include "kernels.h"
 
@@ -211,10 +212,18 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 // the next tile is already being loaded and written, so neither the load latency of a tile's first
 // K-steps nor a workgroup re-launch sits between tiles (with K = 384 a tile is only 12 K-steps:
 // prologue + epilogue + launch gap were half of a one-tile workgroup's lifetime).
-template <int EPI, bool OUT_PLANES>
-__global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const GemmParams g, int n_tiles) {
+// BMT = 128: 4 waves, two workgroups per CU.  BMT = 256: 8 waves (4 x 2 of 64x64), ONE workgroup per CU whose two
+// 128-row halves share the W tile in LDS: 25 % fewer LDS store bytes per MFMA (the kernel is LDS-pipe bound:
+// DESIGN.md §4 finding 6) and one barrier domain per CU.
+template <int EPI, bool OUT_PLANES, int BMT>
+__global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const GemmParams g, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* lds = reinterpret_cast<_Float16*>(smem);
+    constexpr int NTH = BMT * 2, SLOTS = NTH / 8;        // threads; rows covered by one pass of 16-byte pieces
+    constexpr int NA = BMT / SLOTS, NWR = BN / SLOTS;     // A / W rows per thread and K-step (4 / 4 or 4 / 2)
+    constexpr int NLD = NA + NWR;
+    constexpr int STAGE_T = (BMT + BN) * ROW2;            // halves per LDS stage: A rows then W rows
+    constexpr int OPER_T = BMT * ROW2;
 
     const int tiles_n = (g.N + BN - 1) / BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     // pieces = eight consecutive lanes -> whole cache lines, and the same 128 contiguous bytes in LDS.
     // Thread -> rows prow + 32 i (i < 4), piece pc.
     const int slot = tid >> 3, pc = tid & 7;
-    const int prow = ((slot >> 1) & 3) + 4 * (slot & 1) + 8 * (slot >> 3);  // bijection on 0..31
+    const int prow = slot;  // rows prow + SLOTS * i
     const int lds_piece = 8 * pc;
     const int nk = g.K / BK;  // >= 2 (launcher)
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, unsigned(g.M) * unsigned(g.lda) * 4u, 0x00020000);
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     // the loads of items s+2 and s+3 in flight while item s runs from LDS stage s&1 and item s+1 is
     // written to the other stage: the CU has ~128 KB of loads outstanding, which is what it takes to
     // cover the L2 round trip at this tile size (one set = 64 KB in flight measured ~23 B/clk/CU).
-    u32x4 r0[8], r1[8];  // A rows 0..3, W rows 0..3
+    u32x4 r0[NLD], r1[NLD];  // A rows, then W rows
     // Tile order: static round robin over the XCD-remapped workgroup id.  (The two workgroups of a CU do not
     // progress evenly — the first-dispatched one runs ~1.4x faster and the other finishes its share alone — but
     // neither an atomic tile queue nor an unequal static split shortened the launch: DESIGN.md §4, finding 4.)
@@ -250,35 +259,40 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     if (first >= n_tiles) return;
     int ld_ord = 0, ord = 0;
     int ld_tile = first, ld_kt = 0;  // next stream item to load
-    auto load_next = [&](u32x4 (&st)[8]) {
+    auto load_next = [&](u32x4 (&st)[NLD]) {
         {   // branch-free (an item must be ONE basic block for the interleave below): past the end of the
             // stream the last tile is re-loaded and never consumed
             const int lt = ld_tile < n_tiles ? ld_tile : n_tiles - 1;
-            const int m0 = (lt / tiles_n) * BM, n0 = (lt % tiles_n) * BN;
+            const int m0 = (lt / tiles_n) * BMT, n0 = (lt % tiles_n) * BN;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NA; ++i) {
 #ifdef X3_L1ONLY  // timing experiment: every load hits the same few lines (no L2 traffic; wrong results)
-                const unsigned va = unsigned((prow + 32 * i) & 7) * unsigned(g.lda) * 4u + pc * 16u + 0 * m0;
-                const unsigned vw = unsigned((prow + 32 * i) & 7) * unsigned(g.ldw) * 4u + pc * 16u + 0 * n0;
+                const unsigned va = unsigned((prow + SLOTS * i) & 7) * unsigned(g.lda) * 4u + pc * 16u + 0 * m0;
 #else
-                const unsigned va = unsigned(m0 + prow + 32 * i) * unsigned(g.lda) * 4u + pc * 16u;
-                const unsigned vw = unsigned(n0 + prow + 32 * i) * unsigned(g.ldw) * 4u + pc * 16u;
+                const unsigned va = unsigned(m0 + prow + SLOTS * i) * unsigned(g.lda) * 4u + pc * 16u;
 #endif
                 st[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, ld_kt * 128, 0);
-                st[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, ld_kt * 128, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NWR; ++i) {
+#ifdef X3_L1ONLY
+                const unsigned vw = unsigned((prow + SLOTS * i) & 7) * unsigned(g.ldw) * 4u + pc * 16u + 0 * n0;
+#else
+                const unsigned vw = unsigned(n0 + prow + SLOTS * i) * unsigned(g.ldw) * 4u + pc * 16u;
+#endif
+                st[NA + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, ld_kt * 128, 0);
             }
             if (++ld_kt == nk) { ld_kt = 0; ld_tile = tile_of(++ld_ord); }
         }
     };
-    auto write_stage = [&](int s, const u32x4 (&st)[8]) {
-        _Float16* S = lds + s * STAGE2 + lds_piece;
+    auto write_stage = [&](int s, const u32x4 (&st)[NLD]) {
+        _Float16* S = lds + s * STAGE_T + lds_piece;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(S + (prow + 32 * i) * ROW2) = st[i];
-            *reinterpret_cast<u32x4*>(S + OPER2 + (prow + 32 * i) * ROW2) = st[4 + i];
-        }
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(S + (prow + SLOTS * i) * ROW2) = st[i];
+#pragma unroll
+        for (int i = 0; i < NWR; ++i) *reinterpret_cast<u32x4*>(S + OPER_T + (prow + SLOTS * i) * ROW2) = st[NA + i];
     };
-    const int a_off = (wm * 64 + r) * ROW2 + 8 * h, w_off = OPER2 + (wn * 64 + r) * ROW2 + 8 * h;
+    const int a_off = (wm * 64 + r) * ROW2 + 8 * h, w_off = OPER_T + (wn * 64 + r) * ROW2 + 8 * h;
     f32x16 acc[2][2];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
     };
     struct Frags { f16x8 ah[2], al[2], wh[2], wl[2]; };
     auto read_frags = [&](int s, int kg, Frags& f) {
-        const _Float16* S = lds + s * STAGE2;
+        const _Float16* S = lds + s * STAGE_T;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f.ah[t] = *reinterpret_cast<const f16x8*>(S + a_off + t * 32 * ROW2 + kg * 16);
@@ -300,14 +314,31 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
         }
     };
     auto mfma_frags = [&](const Frags& f) {
+        // term-major: consecutive MFMAs go to different accumulators (a chain on one accumulator would wait for the
+        // previous result); small terms first
+#ifdef X3_ACC_MAJOR
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                acc[mi][ni] = mfma_f16(f.wl[ni], f.ah[mi], acc[mi][ni]);  // small terms first
+                acc[mi][ni] = mfma_f16(f.wl[ni], f.ah[mi], acc[mi][ni]);
                 acc[mi][ni] = mfma_f16(f.wh[ni], f.al[mi], acc[mi][ni]);
                 acc[mi][ni] = mfma_f16(f.wh[ni], f.ah[mi], acc[mi][ni]);
             }
+#else
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_f16(f.wl[ni], f.ah[mi], acc[mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_f16(f.wh[ni], f.al[mi], acc[mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_f16(f.wh[ni], f.ah[mi], acc[mi][ni]);
+#endif
     };
     // Epilogue of one tile, branch-free and free of loads between its stores: bias / gamma are per-lane
     // constants of the tile (a lane keeps its four columns for all 16 row pieces) and are fetched once, up
@@ -323,8 +354,89 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
         const_cast<float*>(EPI == EPI_BIAS_LS_RES ? g.res : g.C), 0,
         EPI == EPI_BIAS_LS_RES ? unsigned(g.M) * unsigned(g.ldres) * 4u : 0u, 0x00020000);
     const int ec4 = (lane & 15) * 4, elr = lane >> 4;
+    // 8-wave variant: the staging of eight 32x68 wave tiles does not fit one LDS stage, so each wave transposes one
+    // 32x32 accumulator block at a time through a 32x36-float region (eight lanes per 128-byte row segment).
+    constexpr int EPI_ST2 = 36;
+    static_assert(BMT == 128 || size_t(8) * 32 * EPI_ST2 * sizeof(float) <= size_t(STAGE_T) * sizeof(_Float16), "staging fits a stage");
+    auto epilogue256 = [&](int tile, float* epi) {
+        const int m0 = (tile / tiles_n) * BMT, n0 = (tile % tiles_n) * BN;
+        const int c4 = (lane & 7) * 4, lr = lane >> 3;
+        constexpr float inv = 1.0f / (A_SCALE * W_SCALE);
+        constexpr unsigned DROP = 0xFFFFFF00u;
+        f32x4 bias[2], gamma[2];
+        bool col_ok[2];
+        int col[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            col[ni] = n0 + wn * 64 + ni * 32 + c4;
+            col_ok[ni] = col[ni] < g.N;
+            const int colc = col_ok[ni] ? col[ni] : 0;
+            bias[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gamma[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (g.bias) bias[ni] = *reinterpret_cast<const f32x4*>(g.bias + colc);
+            if constexpr (EPI == EPI_BIAS_LS_RES) {
+                gamma[ni] = *reinterpret_cast<const f32x4*>(g.gamma + colc);
+                bias[ni] = bias[ni] * gamma[ni];
+                gamma[ni] = gamma[ni] * inv;
+            }
+        }
+        __syncthreads();  // all waves have finished reading the last K-step stage
+        float* E = epi + wave * 32 * EPI_ST2;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g4 + e];
+                    *reinterpret_cast<f32x4*>(&E[r * EPI_ST2 + 8 * g4 + 4 * h]) = v;
+                }
+                const unsigned row0 = unsigned(m0 + wm * 64 + mi * 32 + lr);
+                f32x4 res[4];
+                if constexpr (EPI == EPI_BIAS_LS_RES) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        res[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                     rres, col_ok[ni] ? (row0 + 8 * i) * unsigned(g.ldres) * 4u + unsigned(col[ni]) * 4u : DROP, 0, 0));
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&E[(lr + 8 * i) * EPI_ST2 + c4]);
+                    const unsigned off = (row0 + 8 * i) * c_row_bytes;
+                    if constexpr (EPI == EPI_BIAS) {
+                        v = v * inv + bias[ni];
+                    } else if constexpr (EPI == EPI_BIAS_GELU) {
+                        v = v * inv + bias[ni];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_scalar(v[e]);
+                    } else {
+                        v = res[i] + v * gamma[ni] + bias[ni];
+                    }
+                    if constexpr (OUT_PLANES) {
+                        f16x4 hi, lo;
+                        split(v, A_SCALE, hi, lo);
+                        const unsigned o = col_ok[ni] ? off + unsigned((col[ni] >> 5) * 128 + (col[ni] & 31) * 2) : DROP;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rc, o, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rc, o + 64u, 0, 2);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc,
+                                                               col_ok[ni] ? off + unsigned(col[ni]) * 4u : DROP, 0,
+                                                               EPI == EPI_BIAS_LS_RES ? 0 : 2);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        __syncthreads();  // epilogue staging is drained before the stage is written again
+    };
     auto epilogue = [&](int tile, float* epi) {
-        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+        if constexpr (BMT == 256) {
+            epilogue256(tile, epi);
+            return;
+        }
+        const int m0 = (tile / tiles_n) * BMT, n0 = (tile % tiles_n) * BN;
         const int col = n0 + wn * 64 + ec4;
         const bool col_ok = col < g.N;
         const int colc = col_ok ? col : 0;
@@ -424,13 +536,27 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
 #else
     auto stamp = [&](int) {};
 #endif
-    auto item = [&](int s, u32x4 (&nx)[8]) {
+#ifdef X3_NO_FRAGREAD
+    Frags fr0, fr1;
+#endif
+    auto item = [&](int s, u32x4 (&nx)[NLD]) {
         stamp(kt);
         Frags f0, f1;
+#ifdef X3_NO_FRAGREAD  // dev timing experiment (wrong results): fragments are read for the first item only
+        if (s < 1) { read_frags(0, 0, fr0); read_frags(0, 1, fr1); }
+        f0 = fr0; f1 = fr1;
+#else
         read_frags(s & 1, 0, f0);
+#endif
+#ifndef X3_NO_STAGE  // dev timing experiment (wrong results): no staging work in the loop
         write_stage((s + 1) & 1, nx);
         load_next(nx);
+#else
+        if (++ld_kt == nk) { ld_kt = 0; ld_tile = tile_of(++ld_ord); }
+#endif
+#ifndef X3_NO_FRAGREAD
         read_frags(s & 1, 1, f1);
+#endif
         mfma_frags(f0);
         mfma_frags(f1);
 #ifndef X3_NO_SCHED
@@ -442,15 +568,15 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_f16x3_planes_kernel(const 
 #pragma unroll
         for (int i = 0; i < 24; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (i < NLD) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             if (i >= 2 && i < 10) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // f1
-            if (i >= 8 && i < 16) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (i >= 8 && i < 8 + NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
 #endif
         __syncthreads();  // stage (s+1)&1 is published, stage s&1 is free
         if (++kt == nk) {
             stamp(12);
-            epilogue(tile, reinterpret_cast<float*>(lds + (s & 1) * STAGE2));
+            epilogue(tile, reinterpret_cast<float*>(lds + (s & 1) * STAGE_T));
             stamp(13);
 #ifdef X3_STAMPS
             ++tile_ord;
@@ -513,32 +639,44 @@ int pope_lab_gemm_f16x3(const GemmParams& g, int lab, hipStream_t stream) {
     return pope_check_launch();
 }
 
-template <int EPI, bool OUT_PLANES>
-int launch_planes(const GemmParams& g, hipStream_t stream) {
+template <int EPI, bool OUT_PLANES, int BMT>
+int launch_planes_t(const GemmParams& g, hipStream_t stream) {
+    constexpr size_t lds = size_t(2) * (BMT + BN) * ROW2 * sizeof(_Float16);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f16x3_planes_kernel<EPI, OUT_PLANES>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(X3P_LDS_BYTES)) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f16x3_planes_kernel<EPI, OUT_PLANES, BMT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
             return POPE_ERR_LAUNCH;
         attr_set = true;
     }
-    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    const int slots = 2 * pope_cu_count();  // two resident workgroups per CU (2 x 72 KB LDS, 128 VGPRs + 64 AGPRs)
-    hipLaunchKernelGGL((gemm_nt_f16x3_planes_kernel<EPI, OUT_PLANES>), dim3(tiles < slots ? tiles : slots), dim3(THREADS),
-                       X3P_LDS_BYTES, stream, g, tiles);
+    const int tiles = ((g.M + BMT - 1) / BMT) * ((g.N + BN - 1) / BN);
+    // 128-row tiles: two resident workgroups per CU (2 x 72 KB LDS); 256-row tiles: one (108 KB)
+    const int slots = (BMT == 128 ? 2 : 1) * pope_cu_count();
+    hipLaunchKernelGGL((gemm_nt_f16x3_planes_kernel<EPI, OUT_PLANES, BMT>), dim3(tiles < slots ? tiles : slots), dim3(BMT * 2),
+                       lds, stream, g, tiles);
     return pope_check_launch();
+}
+
+template <int EPI, bool OUT_PLANES>
+int launch_planes(const GemmParams& g, hipStream_t stream) {
+    static const int force = getenv("POPE_GEMM_BM") ? atoi(getenv("POPE_GEMM_BM")) : 0;  // dev switch: 128 or 256
+    // Measured (DESIGN.md §4 finding 6): the 256-row kernel moves 25 % fewer LDS store bytes per MFMA and is 2-5 %
+    // faster on QKV / FC1 in isolation, but inside the model (planes outputs, neighbours' cache state) the 128-row
+    // kernel, whose second workgroup runs its K loop under the first one's epilogue, wins on every shape: default.
+    const bool big = force == 256;
+    return big ? launch_planes_t<EPI, OUT_PLANES, 256>(g, stream) : launch_planes_t<EPI, OUT_PLANES, 128>(g, stream);
 }
 
 int pope_launch_gemm_nt_f16x3_planes(const GemmParams& g, hipStream_t stream) {
     static_assert(A_SCALE == K_PLANES_ACT_SCALE && W_SCALE == K_PLANES_W_SCALE, "plane scales");
     if (g.M <= 0 || g.N <= 0 || g.K < 2 * BK || (g.K % BK) || (g.N & 3) || (g.ldc & 3) || (g.lda & 7) || (g.ldw & 7)) return POPE_ERR_ARG;
     if (!g.a_pl || !g.w_pl || (g.lda & 31) || (g.ldw & 31)) return POPE_ERR_ARG;
-    if (size_t(g.M + BM) * g.lda * 4 >= (size_t(1) << 32) || size_t(g.N + BN) * g.ldw * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
+    if (size_t(g.M + 256) * g.lda * 4 >= (size_t(1) << 32) || size_t(g.N + BN) * g.ldw * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
     const bool out_planes = g.c_pl != nullptr;
     if (out_planes ? (g.ldc & 31) != 0 : !g.C) return POPE_ERR_ARG;
     // the epilogue addresses C (and res) through 32-bit buffer offsets
-    if (size_t(g.M + BM) * g.ldc * 4 >= (size_t(1) << 32) - 512) return POPE_ERR_ARG;
-    if (g.epilogue == EPI_BIAS_LS_RES && size_t(g.M + BM) * g.ldres * 4 >= (size_t(1) << 32) - 512) return POPE_ERR_ARG;
+    if (size_t(g.M + 256) * g.ldc * 4 >= (size_t(1) << 32) - 512) return POPE_ERR_ARG;
+    if (g.epilogue == EPI_BIAS_LS_RES && size_t(g.M + 256) * g.ldres * 4 >= (size_t(1) << 32) - 512) return POPE_ERR_ARG;
     switch (g.epilogue) {
         case EPI_BIAS: return out_planes ? launch_planes<EPI_BIAS, true>(g, stream) : launch_planes<EPI_BIAS, false>(g, stream);
         case EPI_BIAS_GELU:
