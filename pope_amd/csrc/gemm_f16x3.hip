@@ -436,6 +436,20 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
             epilogue256(tile, epi);
             return;
         }
+#ifdef X3_NO_EPILOGUE  // dev timing floor (wrong results)
+        {
+            float sum = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sum += acc[mi][ni][e];
+            if (sum == 1234.5f) g.C[0] = 1.f;
+            __syncthreads();
+        }
+        return;
+#endif
         const int m0 = (tile / tiles_n) * BMT, n0 = (tile % tiles_n) * BN;
         const int col = n0 + wn * 64 + ec4;
         const bool col_ok = col < g.N;
