@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define POPE_ABI_VERSION 2
+#define POPE_ABI_VERSION 3
 
 enum {
     POPE_EPI_BIAS = 0,        /* C = A.W^T + bias                         nn.Linear                     */
@@ -80,6 +80,12 @@ int pope_layernorm_planes_f32(const float* x, const float* weight, const float* 
  * the (H/patch, W/patch) grid; tokens[B, ntok, dim], ntok = 1 + (H/patch)*(W/patch). */
 int pope_patch_embed_f32(const float* img, const float* proj_w, const float* posb, float* tokens,
                          int B, int H, int W, int patch, int dim, void* stream);
+/* Same on the f16 matrix cores: the image patches are gathered into activation planes [B*ntok, kp] in
+ * a_planes_scratch (>= B*ntok*kp*4 bytes; kp = 3*patch^2 rounded up to 32) and multiplied with proj_w_planes
+ * [dim, kp] (weight planes, zero-padded columns); posb as above. */
+int pope_patch_embed_planes_f32(const float* img, const void* proj_w_planes, const float* posb, float* tokens,
+                                int B, int H, int W, int patch, int dim, void* a_planes_scratch,
+                                size_t scratch_bytes, void* stream);
 
 /* Attention.forward core — attention.py:51-59: qkv[B,N,3,heads,64] -> out[B,N,heads*64],
  * softmax((q*0.125) k^T) v. */
@@ -116,6 +122,8 @@ typedef struct pope_vit_weights {
     const float *norm_w, *norm_b;         /* final norm                                         */
     const pope_vit_block_weights* blocks_host; /* HOST array [depth] of device-pointer structs  */
     int precision;                        /* POPE_PREC_* of the Linear layers and of attention  */
+    const void* patch_wp;                 /* optional: patch_w as weight planes [dim, kp], kp = 3*patch^2 rounded up to a
+                                             multiple of 32 with zero columns; enables the f16x3 patch embed */
 } pope_vit_weights;
 
 size_t pope_vit_workspace_bytes(int B, int ntok, int dim, int hidden);

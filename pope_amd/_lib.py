@@ -24,7 +24,8 @@ class VitBlockWeights(C.Structure):
 class VitWeights(C.Structure):
     _fields_ = [("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int), ("patch", C.c_int),
                 ("hidden", C.c_int), ("patch_w", C.c_void_p), ("norm_w", C.c_void_p),
-                ("norm_b", C.c_void_p), ("blocks_host", C.POINTER(VitBlockWeights)), ("precision", C.c_int)]
+                ("norm_b", C.c_void_p), ("blocks_host", C.POINTER(VitBlockWeights)), ("precision", C.c_int),
+                ("patch_wp", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/pope_hip.h
@@ -44,6 +45,7 @@ PROTOTYPES = {
     "pope_patch_embed_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "pope_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pope_attention_prec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pope_patch_embed_planes_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "pope_attention_planes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pope_cls_cosine_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "pope_vit_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
@@ -94,7 +96,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.pope_abi_version() != 2:
+        if handle.pope_abi_version() != 3:
             raise RuntimeError("libpope_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -133,6 +133,26 @@ int pope_patch_embed_f32(const float* img, const float* proj_w, const float* pos
     return pope_launch_gemm_nt_f32(g, static_cast<hipStream_t>(stream));
 }
 
+int pope_patch_embed_planes_f32(const float* img, const void* proj_w_planes, const float* posb, float* tokens, int B, int H,
+                                int W, int patch, int dim, void* a_planes_scratch, size_t scratch_bytes, void* stream_) {
+    if (!img || !proj_w_planes || !posb || !tokens || !a_planes_scratch || B <= 0 || patch <= 0 || H % patch || W % patch)
+        return POPE_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int kp = (3 * patch * patch + 31) & ~31, ntok = 1 + (H / patch) * (W / patch);
+    if (scratch_bytes < size_t(B) * ntok * kp * 4) return POPE_ERR_WORKSPACE;
+    int rc = pope_launch_im2col_planes(img, a_planes_scratch, B, H, W, patch, kp, stream);
+    if (rc) return rc;
+    // tokens[b, n] = posb[n] + 1 * (A[b, n] . W^T): rows n = 0 are all-zero A rows (cls_token + pos_embed[0] from the table)
+    GemmParams g = {};
+    g.a_pl = a_planes_scratch; g.w_pl = proj_w_planes;
+    g.C = tokens;
+    g.lda = kp; g.ldw = kp; g.ldc = dim;
+    g.M = B * ntok; g.N = dim; g.K = kp;
+    g.epilogue = EPI_BIAS_LS_RES;
+    g.res = posb; g.ldres = dim; g.res_mod = ntok;
+    return pope_launch_gemm_nt_f16x3_planes(g, stream);
+}
+
 int pope_attention_planes_f32(const void* qkv_planes, void* out_planes, int B, int N, int heads, void* stream) {
     if (!qkv_planes || !out_planes) return POPE_ERR_ARG;
     return pope_launch_attention_f16x3_planes_io(qkv_planes, out_planes, B, N, heads, static_cast<hipStream_t>(stream));
@@ -189,7 +209,12 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
 
 #define POPE_MARK(kind) do { if (!rec.mark(kind, stream)) return POPE_ERR_ARG; } while (0)
     POPE_MARK(POPE_K_PATCH_EMBED);
-    int rc = pope_patch_embed_f32(img, w->patch_w, posb, x, B, H, W, w->patch, dim, stream);
+    int rc;
+    if (prec == POPE_PREC_F16X3 && w->patch_wp && dim % 4 == 0)  // `big` is free here: it holds the im2col planes
+        rc = pope_patch_embed_planes_f32(img, w->patch_wp, posb, x, B, H, W, w->patch, dim, big,
+                                         workspace_bytes - size_t(reinterpret_cast<char*>(big) - ws), stream);
+    else
+        rc = pope_patch_embed_f32(img, w->patch_w, posb, x, B, H, W, w->patch, dim, stream);
     if (rc) return rc;
     for (int i = 0; i < w->depth; ++i) {
         const pope_vit_block_weights& k = w->blocks_host[i];

@@ -352,7 +352,8 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
         OUT_PLANES ? g.c_pl : static_cast<void*>(g.C), 0, unsigned(g.M) * c_row_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(EPI == EPI_BIAS_LS_RES ? g.res : g.C), 0,
-        EPI == EPI_BIAS_LS_RES ? unsigned(g.M) * unsigned(g.ldres) * 4u : 0u, 0x00020000);
+        EPI == EPI_BIAS_LS_RES ? unsigned(g.res_mod > 0 ? g.res_mod : g.M) * unsigned(g.ldres) * 4u : 0u, 0x00020000);
+    auto res_row = [&](unsigned row) -> unsigned { return g.res_mod > 0 ? row % unsigned(g.res_mod) : row; };
     const int ec4 = (lane & 15) * 4, elr = lane >> 4;
     // 8-wave variant: the staging of eight 32x68 wave tiles does not fit one LDS stage, so each wave transposes one
     // 32x32 accumulator block at a time through a 32x36-float region (eight lanes per 128-byte row segment).
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
             gamma[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (g.bias) bias[ni] = *reinterpret_cast<const f32x4*>(g.bias + colc);
             if constexpr (EPI == EPI_BIAS_LS_RES) {
-                gamma[ni] = *reinterpret_cast<const f32x4*>(g.gamma + colc);
+                gamma[ni] = g.gamma ? *reinterpret_cast<const f32x4*>(g.gamma + colc) : f32x4{1.f, 1.f, 1.f, 1.f};
                 bias[ni] = bias[ni] * gamma[ni];
                 gamma[ni] = gamma[ni] * inv;
             }
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         res[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                     rres, col_ok[ni] ? (row0 + 8 * i) * unsigned(g.ldres) * 4u + unsigned(col[ni]) * 4u : DROP, 0, 0));
+                                     rres, col_ok[ni] ? res_row(row0 + 8 * i) * unsigned(g.ldres) * 4u + unsigned(col[ni]) * 4u : DROP, 0, 0));
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
         const int colc = col_ok ? col : 0;
         f32x4 bias = {0.f, 0.f, 0.f, 0.f}, gamma = {0.f, 0.f, 0.f, 0.f};
         if (g.bias) bias = *reinterpret_cast<const f32x4*>(g.bias + colc);
-        if constexpr (EPI == EPI_BIAS_LS_RES) gamma = *reinterpret_cast<const f32x4*>(g.gamma + colc);
+        if constexpr (EPI == EPI_BIAS_LS_RES) gamma = g.gamma ? *reinterpret_cast<const f32x4*>(g.gamma + colc) : f32x4{1.f, 1.f, 1.f, 1.f};
         constexpr float inv = 1.0f / (A_SCALE * W_SCALE);
         if constexpr (EPI == EPI_BIAS_LS_RES) {  // res + (v*inv + bias)*gamma = res + v*(inv*gamma) + bias*gamma
             bias = bias * gamma;
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     res[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                 rres, col_ok ? (row0 + 4 * i) * unsigned(g.ldres) * 4u + unsigned(col) * 4u : DROP, 0, 0));
+                                 rres, col_ok ? res_row(row0 + 4 * i) * unsigned(g.ldres) * 4u + unsigned(col) * 4u : DROP, 0, 0));
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -696,7 +697,7 @@ int pope_launch_gemm_nt_f16x3_planes(const GemmParams& g, hipStream_t stream) {
         case EPI_BIAS_GELU:
             return out_planes ? launch_planes<EPI_BIAS_GELU, true>(g, stream) : launch_planes<EPI_BIAS_GELU, false>(g, stream);
         case EPI_BIAS_LS_RES:
-            if (!g.gamma || !g.res || out_planes) return POPE_ERR_ARG;
+            if (!g.res || out_planes || (!g.gamma && g.res_mod <= 0)) return POPE_ERR_ARG;
             return launch_planes<EPI_BIAS_LS_RES, false>(g, stream);
     }
     return POPE_ERR_ARG;

@@ -21,6 +21,7 @@ struct GemmParams {
     const float* gamma;  // [N]      (EPI_BIAS_LS_RES)
     const float* res;    // [M,ldres](EPI_BIAS_LS_RES; may alias C)
     int ldres;
+    int res_mod;         // > 0: the residual row is (row % res_mod) of a [res_mod, ldres] table (patch embed: pos + bias)
     // f16x3 "planes" operands (gemm_f16x3.hip, planes kernel): a tensor X[rows, ld] kept as two f16
     // planes with X = (hi + lo) / scale (power-of-two scale: activations 8, weights 256).  The planes
     // kernel needs a_pl and w_pl; when c_pl is set its epilogue writes planes (scale 8) instead of fp32 C.
@@ -47,6 +48,9 @@ constexpr float K_PLANES_ACT_SCALE = 8.0f, K_PLANES_W_SCALE = 256.0f;  // == POP
 int pope_launch_layernorm_planes(const float* x, int ldx, const float* w, const float* b, void* y_pl,
                                  int rows, int dim, float eps, hipStream_t stream);
 // Generic fp32 [rows, ld] -> planes converter (ld % 32 == 0).
+// patch embed, f16x3: image [B,3,H,W] -> A planes [B*ntok, kp] (kp = 3*patch^2 rounded up to 32; row b*ntok is the
+// all-zero CLS row, row b*ntok + 1 + n the flattened patch n; zero K padding)
+int pope_launch_im2col_planes(const float* img, void* a_planes, int B, int H, int W, int patch, int kp, hipStream_t stream);
 int pope_launch_split_planes(const float* src, void* pl, int rows, int ld, float scale, hipStream_t stream);
 int pope_launch_gemm_nt_f16x3(const GemmParams& g, hipStream_t stream);
 

@@ -105,7 +105,47 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
+// Patch embed operand: one thread per (row, k pair).  Row b*ntok + 1 + (py*gw + px), k = c*p*p + dy*p + dx reads
+// img[b, c, py*p + dy, px*p + dx] (patch_embed.py:69-82: Conv2d with kernel = stride = patch, flattened row-major).
+__global__ __launch_bounds__(256) void im2col_planes_kernel(const float* __restrict__ img, _Float16* __restrict__ pl,
+                                                             int B, int H, int W, int patch, int kp, int ntok, int gw) {
+    const size_t n2 = size_t(B) * ntok * (kp / 2);
+    const int k_real = 3 * patch * patch, pp = patch * patch;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n2; i += size_t(gridDim.x) * 256) {
+        const size_t row = i / (kp / 2);
+        const int k = int(i - row * (kp / 2)) * 2;
+        const int b = int(row / ntok), t = int(row - size_t(b) * ntok);
+        f32x2 v = {0.f, 0.f};
+        if (t > 0) {
+            const int py = (t - 1) / gw, px = (t - 1) - py * gw;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int kk = k + e;
+                if (kk < k_real) {
+                    const int c = kk / pp, rem = kk - c * pp, dy = rem / patch, dx = rem - dy * patch;
+                    v[e] = img[((size_t(b) * 3 + c) * H + py * patch + dy) * W + px * patch + dx];
+                }
+            }
+        }
+        v = v * K_PLANES_ACT_SCALE;
+        const f16x2 hi = __builtin_convertvector(v, f16x2);
+        _Float16* o = pl + row * 2 * kp + (k >> 5) * 64 + (k & 31);
+        *reinterpret_cast<f16x2*>(o) = hi;
+        *reinterpret_cast<f16x2*>(o + 32) = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
+    }
+}
+
 }  // namespace
+
+int pope_launch_im2col_planes(const float* img, void* a_planes, int B, int H, int W, int patch, int kp, hipStream_t stream) {
+    if (!img || !a_planes || B <= 0 || patch <= 0 || H % patch || W % patch || (kp & 31) || kp < 3 * patch * patch) return POPE_ERR_ARG;
+    const int gw = W / patch, ntok = 1 + (H / patch) * gw;
+    const size_t n2 = size_t(B) * ntok * (kp / 2);
+    const unsigned blocks = unsigned(n2 / 256 + 1 < 65536 ? n2 / 256 + 1 : 65536);
+    hipLaunchKernelGGL(im2col_planes_kernel, dim3(blocks), dim3(256), 0, stream, img, static_cast<_Float16*>(a_planes), B, H, W,
+                       patch, kp, ntok, gw);
+    return pope_check_launch();
+}
 
 int pope_launch_layernorm_planes(const float* x, int ldx, const float* w, const float* b, void* y_pl,
                                  int rows, int dim, float eps, hipStream_t stream) {

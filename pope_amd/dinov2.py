@@ -163,10 +163,14 @@ class DinoVisionTransformer(nn.Module):
                 P(b.mlp.fc1.weight), P(b.mlp.fc1.bias), P(b.mlp.fc2.weight), P(b.mlp.fc2.bias), P(b.ls2.gamma),
                 planes(b.attn.qkv.weight), planes(b.mlp.fc1.weight), planes(b.mlp.fc2.weight),
                 planes(b.attn.proj.weight))
+        pw = self.patch_embed.proj.weight.detach().reshape(self.embed_dim, -1)
+        patch_wp = None
+        if self.precision == "f16x3" and pw.is_cuda:   # [dim, 3*p*p] zero-padded to a multiple of 32 columns
+            kp = (pw.shape[1] + 31) // 32 * 32
+            patch_wp = planes(torch.nn.functional.pad(pw.float(), (0, kp - pw.shape[1])))
         w = _lib.VitWeights(self.embed_dim, self.n_blocks, self.num_heads, self.patch_size,
-                            self.blocks[0].mlp.fc1.weight.shape[0],
-                            P(self.patch_embed.proj.weight.reshape(self.embed_dim, -1)),
-                            P(self.norm.weight), P(self.norm.bias), blocks, _lib.PRECISIONS[self.precision])
+                            self.blocks[0].mlp.fc1.weight.shape[0], P(pw),
+                            P(self.norm.weight), P(self.norm.bias), blocks, _lib.PRECISIONS[self.precision], patch_wp)
         self._wcache = (dev_ptr, w, blocks, tensors, self.precision)
         return w
 
@@ -258,7 +262,8 @@ class DinoVisionTransformer(nn.Module):
         B, nc, H, W = x.shape
         ntok = 1 + (H // self.patch_size) * (W // self.patch_size)
         self._weights()
-        return ops.patch_embed(x, self.patch_embed.proj.weight.detach(), self._posb(H, W, ntok), self.patch_size)
+        return ops.patch_embed(x, self.patch_embed.proj.weight.detach(), self._posb(H, W, ntok), self.patch_size,
+                               precision=self.precision)
 
     def forward_features(self, x, masks=None):
         if isinstance(x, list):

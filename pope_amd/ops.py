@@ -41,8 +41,9 @@ def linear(a, weight, bias=None, epilogue=EPI_BIAS, gamma=None, res=None, out=No
     return out
 
 
-def patch_embed(img, proj_w, posb, patch):
-    """PatchEmbed + cls + pos (patch_embed.py:69-82, vision_transformer.py:191-200)."""
+def patch_embed(img, proj_w, posb, patch, precision="f32"):
+    """PatchEmbed + cls + pos (patch_embed.py:69-82, vision_transformer.py:191-200).  precision="f16x3": patches are
+    gathered into hi/lo f16 planes and multiplied on the f16 matrix cores (3 MFMAs per product, fp32 accumulate)."""
     img = _f32c(img, "patch_embed")
     b, c, h, w = img.shape
     assert c == 3
@@ -52,7 +53,16 @@ def patch_embed(img, proj_w, posb, patch):
     ntok = 1 + (h // patch) * (w // patch)
     assert posb.shape == (ntok, dim)
     out = torch.empty(b, ntok, dim, device=img.device, dtype=torch.float32)
-    check(_lib.lib().pope_patch_embed_f32(ptr(img), ptr(_f32c(proj_w.reshape(dim, -1), "pe.w")), ptr(_f32c(posb, "posb")),
+    pw = _f32c(proj_w.reshape(dim, -1), "pe.w")
+    if precision == "f16x3":
+        kp = (pw.shape[1] + 31) // 32 * 32
+        wp = _lib.to_planes(torch.nn.functional.pad(pw, (0, kp - pw.shape[1])), _lib.PLANES_W_SCALE)
+        scratch = torch.empty(b * ntok * kp * 4, dtype=torch.uint8, device=img.device)
+        check(_lib.lib().pope_patch_embed_planes_f32(ptr(img), ptr(wp), ptr(_f32c(posb, "posb")), ptr(out), b, h, w, patch,
+                                                     dim, ptr(scratch), scratch.numel(), stream_of(img.device)),
+              "pope_patch_embed_planes_f32")
+        return out
+    check(_lib.lib().pope_patch_embed_f32(ptr(img), ptr(pw), ptr(_f32c(posb, "posb")),
                                           ptr(out), b, h, w, patch, dim, stream_of(img.device)), "pope_patch_embed_f32")
     return out
 

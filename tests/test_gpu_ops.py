@@ -96,12 +96,14 @@ def test_linear_layerscale_residual_inplace(dev, prec):
     _close(got, want, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B,H,W", [(2, 28, 42), (1, 196, 196), (2, 224, 224), (1, 476, 630)])
-def test_patch_embed_tokens(dev, sd0, B, H, W):
+def test_patch_embed_tokens(dev, sd0, B, H, W, prec):
     from oracle import dinov2_ref
     from pope_amd import synth
     from pope_amd.dinov2_utils import load_dinov2_model
     model = load_dinov2_model(state_dict=sd0).to(dev)
+    model.precision = prec
     x = synth.synthetic_images(B, H, W, seed=21)
     want = dinov2_ref.prepare_tokens(sd0, x)
     got = model.prepare_tokens_with_masks(x.to(dev))
