@@ -182,6 +182,16 @@ int pope_dense_match_f32(const float* feat0, long long stride0, const float* fea
                          float scale, float* conf_matrix, long long* b_ids, long long* i_ids,
                          long long* j_ids, float* mconf, float* mkpts0_c, float* mkpts1_c, int* counts,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* Same with an explicit POPE_PREC_* for the L x S x C contraction (pope_dense_match_f32 == POPE_PREC_F32_MFMA).
+ * POPE_PREC_F16X3 needs C % 32 == 0 and the larger workspace of pope_dense_match_workspace_bytes_prec (the two
+ * feature tensors as hi/lo planes of feat / sqrt(C)); everything after the contraction is identical. */
+size_t pope_dense_match_workspace_bytes_prec(int n, int L, int S, int C, int precision);
+int pope_dense_match_prec_f32(const float* feat0, long long stride0, const float* feat1, long long stride1,
+                              int n, int L, int S, int C, int h0, int w0, int h1, int w1,
+                              float thr, int border_rm, float temperature, float scale,
+                              float* conf_matrix, long long* b_ids, long long* i_ids, long long* j_ids,
+                              float* mconf, float* mkpts0_c, float* mkpts1_c, int* counts,
+                              void* workspace, size_t workspace_bytes, int precision, void* stream);
 
 /* ---- host-side helper ------------------------------------------------------------------------ */
 

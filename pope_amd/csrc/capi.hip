@@ -343,14 +343,31 @@ size_t pope_dense_match_workspace_bytes(int n, int L, int S) {
     return 5 * nl + 3 * ns;  // row_max,row_sum,conf_rowmax,row_j,row_conf | col_max,col_sum,conf_colmax
 }
 
+size_t pope_dense_match_workspace_bytes_prec(int n, int L, int S, int C, int precision) {
+    const size_t base = pope_dense_match_workspace_bytes(n, L, S);
+    if (!base || C <= 0) return 0;
+    if (precision != POPE_PREC_F16X3) return base;
+    return base + align_up(size_t(n) * L * C * 4, 256) + align_up(size_t(n) * S * C * 4, 256);
+}
+
 int pope_dense_match_f32(const float* feat0, long long stride0, const float* feat1, long long stride1, int n, int L,
                          int S, int C, int h0, int w0, int h1, int w1, float thr, int border_rm, float temperature, float scale, float* conf_matrix,
                          long long* b_ids, long long* i_ids, long long* j_ids, float* mconf, float* mkpts0_c,
                          float* mkpts1_c, int* counts, void* workspace, size_t workspace_bytes, void* stream) {
+    return pope_dense_match_prec_f32(feat0, stride0, feat1, stride1, n, L, S, C, h0, w0, h1, w1, thr, border_rm, temperature, scale,
+                                     conf_matrix, b_ids, i_ids, j_ids, mconf, mkpts0_c, mkpts1_c, counts, workspace,
+                                     workspace_bytes, POPE_PREC_F32_MFMA, stream);
+}
+
+int pope_dense_match_prec_f32(const float* feat0, long long stride0, const float* feat1, long long stride1, int n, int L,
+                              int S, int C, int h0, int w0, int h1, int w1, float thr, int border_rm, float temperature, float scale, float* conf_matrix,
+                              long long* b_ids, long long* i_ids, long long* j_ids, float* mconf, float* mkpts0_c,
+                              float* mkpts1_c, int* counts, void* workspace, size_t workspace_bytes, int precision, void* stream) {
     if (!feat0 || !feat1 || !conf_matrix || !b_ids || !i_ids || !j_ids || !mconf || !mkpts0_c || !mkpts1_c ||
         !counts || !workspace)
         return POPE_ERR_ARG;
-    if (workspace_bytes < pope_dense_match_workspace_bytes(n, L, S)) return POPE_ERR_WORKSPACE;
+    if (precision != POPE_PREC_F32_MFMA && precision != POPE_PREC_F16X3) return POPE_ERR_ARG;
+    if (workspace_bytes < pope_dense_match_workspace_bytes_prec(n, L, S, C, precision)) return POPE_ERR_WORKSPACE;
     const size_t nl = align_up(size_t(n) * L * 4, 256), ns = align_up(size_t(n) * S * 4, 256);
     char* ws = static_cast<char*>(workspace);
     MatchParams p = {};
@@ -368,6 +385,10 @@ int pope_dense_match_f32(const float* feat0, long long stride0, const float* fea
     p.col_max = reinterpret_cast<float*>(ws + 5 * nl);
     p.col_sum = reinterpret_cast<float*>(ws + 5 * nl + ns);
     p.conf_colmax = reinterpret_cast<unsigned*>(ws + 5 * nl + 2 * ns);
+    if (precision == POPE_PREC_F16X3) {
+        p.planes0 = ws + 5 * nl + 3 * ns;
+        p.planes1 = ws + 5 * nl + 3 * ns + align_up(size_t(n) * L * C * 4, 256);
+    }
     p.counts = counts;
     p.b_ids = b_ids; p.i_ids = i_ids; p.j_ids = j_ids;
     p.mconf = mconf; p.mkpts0 = mkpts0_c; p.mkpts1 = mkpts1_c;

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
     constexpr int OPER_T = BMT * ROW2;
 
     const int tiles_n = (g.N + BN - 1) / BN;
+    const int tiles_pb = ((g.M + BMT - 1) / BMT) * tiles_n;  // tiles per batch (EPI_SIM)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
     // Staging: a row's K-step is 128 contiguous bytes in memory ([32 hi | 32 lo] halves) = eight 16-byte
@@ -235,8 +236,9 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
     const int prow = slot;  // rows prow + SLOTS * i
     const int lds_piece = 8 * pc;
     const int nk = g.K / BK;  // >= 2 (launcher)
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, unsigned(g.M) * unsigned(g.lda) * 4u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, unsigned(g.N) * unsigned(g.ldw) * 4u, 0x00020000);
+    const unsigned nb = EPI == EPI_SIM ? unsigned(g.nbatch) : 1u;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, nb * unsigned(g.M) * unsigned(g.lda) * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, nb * unsigned(g.N) * unsigned(g.ldw) * 4u, 0x00020000);
     // K-steps of this workgroup's tiles form ONE stream (item = (tile, kt)); two register sets keep
     // the loads of items s+2 and s+3 in flight while item s runs from LDS stage s&1 and item s+1 is
     // written to the other stage: the CU has ~128 KB of loads outstanding, which is what it takes to
@@ -263,7 +265,15 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
         {   // branch-free (an item must be ONE basic block for the interleave below): past the end of the
             // stream the last tile is re-loaded and never consumed
             const int lt = ld_tile < n_tiles ? ld_tile : n_tiles - 1;
-            const int m0 = (lt / tiles_n) * BMT, n0 = (lt % tiles_n) * BN;
+            int m0, n0;
+            if constexpr (EPI == EPI_SIM) {  // batched: rows of batch b start at b * M (A) / b * N (W)
+                const int b = lt / tiles_pb, rem = lt - b * tiles_pb;
+                m0 = b * g.M + (rem / tiles_n) * BMT;
+                n0 = b * g.N + (rem % tiles_n) * BN;
+            } else {
+                m0 = (lt / tiles_n) * BMT;
+                n0 = (lt % tiles_n) * BN;
+            }
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
 #ifdef X3_L1ONLY  // timing experiment: every load hits the same few lines (no L2 traffic; wrong results)
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
     // The residual variant needs one load per piece: fetched eight at a time, two drain points per tile.
     const unsigned c_row_bytes = unsigned(g.ldc) * 4u;  // fp32 rows and planes rows have the same pitch
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-        OUT_PLANES ? g.c_pl : static_cast<void*>(g.C), 0, unsigned(g.M) * c_row_bytes, 0x00020000);
+        OUT_PLANES ? g.c_pl : static_cast<void*>(g.C), 0, nb * unsigned(g.M) * c_row_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(EPI == EPI_BIAS_LS_RES ? g.res : g.C), 0,
         EPI == EPI_BIAS_LS_RES ? unsigned(g.res_mod > 0 ? g.res_mod : g.M) * unsigned(g.ldres) * 4u : 0u, 0x00020000);
@@ -435,6 +445,52 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
     auto epilogue = [&](int tile, float* epi) {
         if constexpr (BMT == 256) {
             epilogue256(tile, epi);
+            return;
+        }
+        if constexpr (EPI == EPI_SIM) {
+            // similarity tile of batch b: (acc * alpha) / divisor -> C[b][row][col]; rows >= M and columns >= N belong
+            // to the next batch's operands (or the zero fill) and are dropped; N even: 8-byte stores
+            const int b = tile / tiles_pb, rem = tile - b * tiles_pb;
+            const int m0s = (rem / tiles_n) * BMT, n0s = (rem % tiles_n) * BN;
+            const int cols = n0s + wn * 64 + ec4;
+            constexpr unsigned DROPS = 0xFFFFFF00u;
+            __syncthreads();
+            float* Es = epi + wave * 32 * EPI_ST;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g4 + e];
+                        *reinterpret_cast<f32x4*>(&Es[r * EPI_ST + ni * 32 + 8 * g4 + 4 * h]) = v;
+                    }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&Es[(elr + 4 * i) * EPI_ST + ec4]);
+                    const int row = m0s + wm * 64 + mi * 32 + elr + 4 * i;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] * g.alpha) / g.divisor;
+                    const unsigned off = (unsigned(b) * unsigned(g.M) + unsigned(row)) * c_row_bytes + unsigned(cols) * 4u;
+                    const bool row_ok = row < g.M;
+                    if (!(g.N & 1)) {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{v[0], v[1]}), rc,
+                                                              row_ok && cols + 1 < g.N ? off : DROPS, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{v[2], v[3]}), rc,
+                                                              row_ok && cols + 3 < g.N ? off + 8u : DROPS, 0, 2);
+                    } else {  // odd row length: rows are only 4-byte aligned, plain element stores
+                        float* cp = g.C + (size_t(b) * g.M + row) * g.N + cols;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (row_ok && cols + e < g.N) __builtin_nontemporal_store(v[e], cp + e);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
             return;
         }
 #ifdef X3_NO_EPILOGUE  // dev timing floor (wrong results)
@@ -655,7 +711,7 @@ int pope_lab_gemm_f16x3(const GemmParams& g, int lab, hipStream_t stream) {
 }
 
 template <int EPI, bool OUT_PLANES, int BMT>
-int launch_planes_t(const GemmParams& g, hipStream_t stream) {
+int launch_planes_t(const GemmParams& g, hipStream_t stream, int nbatch = 1) {
     constexpr size_t lds = size_t(2) * (BMT + BN) * ROW2 * sizeof(_Float16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -664,7 +720,7 @@ int launch_planes_t(const GemmParams& g, hipStream_t stream) {
             return POPE_ERR_LAUNCH;
         attr_set = true;
     }
-    const int tiles = ((g.M + BMT - 1) / BMT) * ((g.N + BN - 1) / BN);
+    const int tiles = nbatch * ((g.M + BMT - 1) / BMT) * ((g.N + BN - 1) / BN);
     // 128-row tiles: two resident workgroups per CU (2 x 72 KB LDS); 256-row tiles: one (108 KB)
     const int slots = (BMT == 128 ? 2 : 1) * pope_cu_count();
     hipLaunchKernelGGL((gemm_nt_f16x3_planes_kernel<EPI, OUT_PLANES, BMT>), dim3(tiles < slots ? tiles : slots), dim3(BMT * 2),
@@ -680,6 +736,17 @@ int launch_planes(const GemmParams& g, hipStream_t stream) {
     // kernel, whose second workgroup runs its K loop under the first one's epilogue, wins on every shape: default.
     const bool big = force == 256;
     return big ? launch_planes_t<EPI, OUT_PLANES, 256>(g, stream) : launch_planes_t<EPI, OUT_PLANES, 128>(g, stream);
+}
+
+// Batched similarity for the dense matcher: C[b] = (A[b] . W[b]^T * alpha) / divisor on planes operands.
+int pope_launch_sim_f16x3_planes(const GemmParams& g, hipStream_t stream) {
+    if (g.epilogue != EPI_SIM || !g.a_pl || !g.w_pl || !g.C || g.nbatch <= 0 || g.M <= 0 || g.N <= 0) return POPE_ERR_ARG;
+    if (g.K < 2 * BK || (g.K % BK) || (g.lda & 31) || (g.ldw & 31) || g.ldc != g.N || g.divisor == 0.f) return POPE_ERR_ARG;
+    if ((size_t(g.nbatch) * g.M + BM) * g.lda * 4 >= (size_t(1) << 32) || (size_t(g.nbatch) * g.N + BN) * g.ldw * 4 >= (size_t(1) << 32) ||
+        (size_t(g.nbatch) * g.M + BM) * g.ldc * 4 >= (size_t(1) << 32) - 512)
+        return POPE_ERR_ARG;
+    if (static_cast<long long>(g.nbatch) * ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) > 0x7fffffffLL) return POPE_ERR_ARG;
+    return launch_planes_t<EPI_SIM, false, 128>(g, stream, g.nbatch);
 }
 
 int pope_launch_gemm_nt_f16x3_planes(const GemmParams& g, hipStream_t stream) {

@@ -8,6 +8,7 @@ enum GemmEpilogue {
     EPI_BIAS_GELU = 1,    // C = gelu_erf(A.W^T + bias)
     EPI_BIAS_LS_RES = 2,  // C = res + gamma * (A.W^T + bias)      (LayerScale + residual)
     EPI_POSB = 3,         // patch embed: C = im2col(img).W^T + posb[token]   (A = image)
+    EPI_SIM = 4,          // batched similarity (planes kernel): C[b] = (A[b].W[b]^T * alpha) / divisor, no bias
 };
 
 struct GemmParams {
@@ -21,6 +22,10 @@ struct GemmParams {
     const float* gamma;  // [N]      (EPI_BIAS_LS_RES)
     const float* res;    // [M,ldres](EPI_BIAS_LS_RES; may alias C)
     int ldres;
+    // EPI_SIM: nbatch problems of [rows_a x rows_w x K]; A planes [nbatch*rows_a, lda], W planes [nbatch*rows_w, ldw],
+    // C [nbatch, rows_a, rows_w] fp32 (ldc = rows_w); M = rows_a, N = rows_w
+    int nbatch;
+    float alpha, divisor;
     int res_mod;         // > 0: the residual row is (row % res_mod) of a [res_mod, ldres] table (patch embed: pos + bias)
     // f16x3 "planes" operands (gemm_f16x3.hip, planes kernel): a tensor X[rows, ld] kept as two f16
     // planes with X = (hi + lo) / scale (power-of-two scale: activations 8, weights 256).  The planes
@@ -42,6 +47,7 @@ int pope_launch_gemm_nt_f32(const GemmParams& g, hipStream_t stream);
 bool pope_gemm_f16x3_supported(const GemmParams& g);
 // Planes variant: W (and optionally A / C) as pre-split f16 planes, no splitting in the K loop.
 int pope_launch_gemm_nt_f16x3_planes(const GemmParams& g, hipStream_t stream);
+int pope_launch_sim_f16x3_planes(const GemmParams& g, hipStream_t stream);  // EPI_SIM, batched
 constexpr float K_PLANES_ACT_SCALE = 8.0f, K_PLANES_W_SCALE = 256.0f;  // == POPE_PLANES_*_SCALE of pope_hip.h
 
 // y = LayerNorm(x) written as f16 planes (scale POPE_PLANES_ACT_SCALE), [rows, dim] halves each.
@@ -51,6 +57,10 @@ int pope_launch_layernorm_planes(const float* x, int ldx, const float* w, const 
 // patch embed, f16x3: image [B,3,H,W] -> A planes [B*ntok, kp] (kp = 3*patch^2 rounded up to 32; row b*ntok is the
 // all-zero CLS row, row b*ntok + 1 + n the flattened patch n; zero K padding)
 int pope_launch_im2col_planes(const float* img, void* a_planes, int B, int H, int W, int patch, int kp, hipStream_t stream);
+// matcher operand: planes of feat / divisor (a true fp32 division, coarse_matching.py:109) for n blocks of `rows` rows
+// with `bs` elements between blocks; output compact [n*rows, cols]
+int pope_launch_div_planes(const float* src, long long bs, void* planes, int n, int rows, int cols, float divisor, float scale,
+                           hipStream_t stream);
 int pope_launch_split_planes(const float* src, void* pl, int rows, int ld, float scale, hipStream_t stream);
 int pope_launch_gemm_nt_f16x3(const GemmParams& g, hipStream_t stream);
 
@@ -76,6 +86,7 @@ struct MatchParams {
     int border;
     float scale;         // hw0_i[0] / hw0_c[0]
     float* sim;          // [n, L, S] workspace (sim, then conf in place)
+    void* planes0; void* planes1;  // optional scratch [n*L*C] / [n*S*C] floats-worth: similarity on the f16 matrix cores
     float* row_max; float* row_sum;  // [n, L]
     float* col_max; float* col_sum;  // [n, S]
     unsigned* conf_colmax;           // [n, S] (float bits, conf > 0)

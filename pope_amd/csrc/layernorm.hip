@@ -105,6 +105,22 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void div_planes_kernel(const float* __restrict__ src, long long bs, _Float16* __restrict__ pl,
+                                                          int n, int rows, int cols, float divisor, float scale) {
+    const size_t per = size_t(rows) * cols / 2, n2 = per * n;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n2; i += size_t(gridDim.x) * 256) {
+        const size_t b = i / per, e = (i - b * per) * 2, row = e / cols;
+        const int c = int(e - row * cols);
+        f32x2 y = *reinterpret_cast<const f32x2*>(src + b * bs + e);
+        y[0] = (y[0] / divisor) * scale;   // the division first, exactly as the reference rounds it; scale is a power of two
+        y[1] = (y[1] / divisor) * scale;
+        const f16x2 hi = __builtin_convertvector(y, f16x2);
+        _Float16* o = pl + (b * rows + row) * 2 * cols + (c >> 5) * 64 + (c & 31);
+        *reinterpret_cast<f16x2*>(o) = hi;
+        *reinterpret_cast<f16x2*>(o + 32) = __builtin_convertvector(y - __builtin_convertvector(hi, f32x2), f16x2);
+    }
+}
+
 // Patch embed operand: one thread per (row, k pair).  Row b*ntok + 1 + (py*gw + px), k = c*p*p + dy*p + dx reads
 // img[b, c, py*p + dy, px*p + dx] (patch_embed.py:69-82: Conv2d with kernel = stride = patch, flattened row-major).
 __global__ __launch_bounds__(256) void im2col_planes_kernel(const float* __restrict__ img, _Float16* __restrict__ pl,
@@ -136,6 +152,16 @@ __global__ __launch_bounds__(256) void im2col_planes_kernel(const float* __restr
 }
 
 }  // namespace
+
+int pope_launch_div_planes(const float* src, long long bs, void* planes, int n, int rows, int cols, float divisor, float scale,
+                           hipStream_t stream) {
+    if (!src || !planes || n <= 0 || rows <= 0 || cols <= 0 || (cols & 31) || (bs & 1) || bs < (long long)rows * cols) return POPE_ERR_ARG;
+    const size_t n2 = size_t(n) * rows * cols / 2;
+    const unsigned blocks = unsigned(n2 / 256 + 1 < 65536 ? n2 / 256 + 1 : 65536);
+    hipLaunchKernelGGL(div_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, bs, static_cast<_Float16*>(planes), n, rows,
+                       cols, divisor, scale);
+    return pope_check_launch();
+}
 
 int pope_launch_im2col_planes(const float* img, void* a_planes, int B, int H, int W, int patch, int kp, hipStream_t stream) {
     if (!img || !a_planes || B <= 0 || patch <= 0 || H % patch || W % patch || (kp & 31) || kp < 3 * patch * patch) return POPE_ERR_ARG;

@@ -233,8 +233,28 @@ int pope_launch_dense_match_f32(const MatchParams& p, hipStream_t stream) {
     if (p.L != p.h0 * p.w0 || p.S != p.h1 * p.w1) return POPE_ERR_ARG;
     if (p.bs0 < (long long)p.L * p.C || p.bs1 < (long long)p.S * p.C || (p.bs0 & 3) || (p.bs1 & 3)) return POPE_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(p.feat0) & 15) || (reinterpret_cast<uintptr_t>(p.feat1) & 15)) return POPE_ERR_ARG;
-    const int tiles = ((p.L + BM - 1) / BM) * ((p.S + BN - 1) / BN);
-    hipLaunchKernelGGL(sim_kernel, dim3(tiles, p.n), dim3(THREADS), LDS_BYTES, stream, p, 0.f);
+    bool sim_done = false;
+    if (p.planes0 && p.planes1 && (p.C & 31) == 0 && p.C >= 64) {
+        // f16x3: (f0 / sqrt(C)) and (f1 / sqrt(C)) as hi/lo planes (x256), one batched planes GEMM, (acc / 2^16) / T
+        const float norm = sqrtf(float(p.C));
+        int rc = pope_launch_div_planes(p.feat0, p.bs0, p.planes0, p.n, p.L, p.C, norm, K_PLANES_W_SCALE, stream);
+        if (!rc) rc = pope_launch_div_planes(p.feat1, p.bs1, p.planes1, p.n, p.S, p.C, norm, K_PLANES_W_SCALE, stream);
+        if (rc) return rc;
+        GemmParams g = {};
+        g.a_pl = p.planes0; g.w_pl = p.planes1; g.C = p.sim;
+        g.M = p.L; g.N = p.S; g.K = p.C; g.lda = p.C; g.ldw = p.C; g.ldc = p.S;
+        g.nbatch = p.n;
+        g.alpha = 1.0f / (K_PLANES_W_SCALE * K_PLANES_W_SCALE);
+        g.divisor = p.temperature;
+        g.epilogue = EPI_SIM;
+        rc = pope_launch_sim_f16x3_planes(g, stream);
+        if (rc == 0) sim_done = true;
+        else if (rc != POPE_ERR_ARG) return rc;  // shapes beyond the 32-bit offsets: the fp32 kernel below
+    }
+    if (!sim_done) {
+        const int tiles = ((p.L + BM - 1) / BM) * ((p.S + BN - 1) / BN);
+        hipLaunchKernelGGL(sim_kernel, dim3(tiles, p.n), dim3(THREADS), LDS_BYTES, stream, p, 0.f);
+    }
     const dim3 rows((p.L + 3) / 4, p.n), cols((p.S + 63) / 64, p.n);
     hipLaunchKernelGGL(row_stats_kernel, rows, dim3(256), 0, stream, p);
     hipLaunchKernelGGL(col_reduce_kernel<0>, cols, dim3(256), 0, stream, p);

@@ -34,8 +34,11 @@ def _rows_contiguous(f):
     return f.contiguous()
 
 
+DEFAULT_PRECISION = "f16x3"   # arithmetic of the L x S x C contraction ("f32": fp32-in MFMA); see DESIGN.md §2
+
+
 @torch.no_grad()
-def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, temperature=0.1):
+def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, temperature=0.1, precision=None):
     """All-pairs similarity -> dual softmax -> threshold/border/mutual-NN -> ordered matches.
 
     feat0 [n,L,C], feat1 [n,S,C] fp32 on the GPU.  Returns the dict CoarseMatching publishes
@@ -54,7 +57,11 @@ def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, tempera
     assert feat1.shape[0] == n and feat1.shape[2] == Cc and L == h0 * w0 and S == h1 * w1
     dev = feat0.device
     lib = _lib.lib()
-    ws_bytes = lib.pope_dense_match_workspace_bytes(n, L, S)
+    precision = precision or DEFAULT_PRECISION
+    if Cc % 32 or Cc < 64:
+        precision = "f32"   # the planes layout needs whole 32-column chunks
+    prec = _lib.PRECISIONS[precision]
+    ws_bytes = lib.pope_dense_match_workspace_bytes_prec(n, L, S, Cc, prec)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     conf = torch.empty(n, L, S, dtype=torch.float32, device=dev)
     cap = n * L
@@ -66,11 +73,11 @@ def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, tempera
     mk1 = torch.empty(cap, 2, dtype=torch.float32, device=dev)
     counts = torch.empty(n + 1, dtype=torch.int32, device=dev)
     scale = hw0_i[0] / hw0_c[0]  # coarse_matching.py:242 (heights only)
-    check(lib.pope_dense_match_f32(C.c_void_p(feat0.data_ptr()), feat0.stride(0), C.c_void_p(feat1.data_ptr()),
-                                   feat1.stride(0), n, L, S, Cc, h0, w0, h1, w1, float(thr), int(border_rm),
-                                   float(temperature), float(scale), ptr(conf), ptr(b_ids), ptr(i_ids), ptr(j_ids),
-                                   ptr(mconf), ptr(mk0), ptr(mk1), ptr(counts), C.c_void_p(ws.data_ptr()), ws_bytes,
-                                   stream_of(dev)), "pope_dense_match_f32")
+    check(lib.pope_dense_match_prec_f32(C.c_void_p(feat0.data_ptr()), feat0.stride(0), C.c_void_p(feat1.data_ptr()),
+                                        feat1.stride(0), n, L, S, Cc, h0, w0, h1, w1, float(thr), int(border_rm),
+                                        float(temperature), float(scale), ptr(conf), ptr(b_ids), ptr(i_ids), ptr(j_ids),
+                                        ptr(mconf), ptr(mk0), ptr(mk1), ptr(counts), C.c_void_p(ws.data_ptr()), ws_bytes,
+                                        prec, stream_of(dev)), "pope_dense_match_prec_f32")
     counts_h = counts.cpu()  # sync point
     m = int(counts_h[n])
     b_ids, i_ids, j_ids, mconf = b_ids[:m], i_ids[:m], j_ids[:m], mconf[:m]

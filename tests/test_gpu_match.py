@@ -15,6 +15,15 @@ def dev(hip_lib):
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True, params=["f16x3", "f32"])
+def contraction_precision(request, monkeypatch):
+    """Every test of this module runs with both arithmetic modes of the L x S x C contraction (same fixtures, same
+    bit-exact index requirements)."""
+    import pope_amd.matcher as m
+    monkeypatch.setattr(m, "DEFAULT_PRECISION", request.param)
+    return request.param
+
+
 def test_loftr_shaped_fixture_indices_identical(dev, golden_dir):
     from pope_amd.matcher import dense_match
     fx = np.load(os.path.join(golden_dir, "match_loftr256.npz"))
