@@ -92,6 +92,59 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __re
     }
 }
 
+// Same, two rows per wave (one per 32-lane half), 16-byte loads: dim = NV4 * 128 <= 512.  The 8-byte loads of the
+// wave-per-row version reach 5.0 TB/s; a float4 copy reaches 6.3 on this chip.
+typedef _Float16 f16x4_ln __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+template <int NV4>
+__global__ __launch_bounds__(256) void layernorm_planes_half_kernel(const float* __restrict__ x, int ldx,
+                                                                     const float* __restrict__ w,
+                                                                     const float* __restrict__ b,
+                                                                     _Float16* __restrict__ ypl, int rows, float eps,
+                                                                     float scale) {
+    const int l = threadIdx.x & 31;
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool live = row < rows;
+    const float* xr = x + size_t(live ? row : 0) * ldx;
+    f32x4 v[NV4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(xr + i * 128 + l * 4);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    constexpr float inv_d = 1.0f / float(NV4 * 128);
+    const float mean = half_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            q += d * d;
+        }
+    const float rstd = 1.0f / sqrtf(half_sum(q) * inv_d + eps);
+    if (!live) return;
+    _Float16* yr = ypl + size_t(row) * (2 * NV4 * 128);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = i * 128 + l * 4;
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = ((v[i][e] - mean) * rstd * ww[e] + bb[e]) * scale;
+        const f16x4_ln hi = __builtin_convertvector(y, f16x4_ln);
+        const f16x4_ln lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x4), f16x4_ln);
+        *reinterpret_cast<f16x4_ln*>(yr + (c >> 5) * 64 + (c & 31)) = hi;
+        *reinterpret_cast<f16x4_ln*>(yr + (c >> 5) * 64 + 32 + (c & 31)) = lo;
+    }
+}
+
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, _Float16* __restrict__ pl,
                                                             size_t n2, int ld, float scale) {
     for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n2; i += size_t(gridDim.x) * 256) {
@@ -176,8 +229,19 @@ int pope_launch_im2col_planes(const float* img, void* a_planes, int B, int H, in
 int pope_launch_layernorm_planes(const float* x, int ldx, const float* w, const float* b, void* y_pl,
                                  int rows, int dim, float eps, hipStream_t stream) {
     if (rows <= 0 || dim <= 0 || (dim & 127) || dim > 2048 || (ldx & 1) || !y_pl) return POPE_ERR_ARG;
-    const dim3 grid((rows + 3) / 4), block(256);
     _Float16* ypl = static_cast<_Float16*>(y_pl);
+    if (dim <= 512 && !(ldx & 3) && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(w) & 15) &&
+        !(reinterpret_cast<uintptr_t>(b) & 15)) {  // two rows per wave, 16-byte accesses
+        const dim3 g8((rows + 7) / 8), b256(256);
+        switch (dim / 128) {
+            case 1: hipLaunchKernelGGL(layernorm_planes_half_kernel<1>, g8, b256, 0, stream, x, ldx, w, b, ypl, rows, eps, K_PLANES_ACT_SCALE); break;
+            case 2: hipLaunchKernelGGL(layernorm_planes_half_kernel<2>, g8, b256, 0, stream, x, ldx, w, b, ypl, rows, eps, K_PLANES_ACT_SCALE); break;
+            case 3: hipLaunchKernelGGL(layernorm_planes_half_kernel<3>, g8, b256, 0, stream, x, ldx, w, b, ypl, rows, eps, K_PLANES_ACT_SCALE); break;
+            default: hipLaunchKernelGGL(layernorm_planes_half_kernel<4>, g8, b256, 0, stream, x, ldx, w, b, ypl, rows, eps, K_PLANES_ACT_SCALE); break;
+        }
+        return pope_check_launch();
+    }
+    const dim3 grid((rows + 3) / 4), block(256);
 #define POPE_LNP_CASE(NV)                                                                                    \
     case NV:                                                                                                 \
         hipLaunchKernelGGL(layernorm_planes_kernel<NV>, grid, block, 0, stream, x, ldx, w, b, ypl, rows, eps,    \
