@@ -28,7 +28,13 @@ constexpr int QB = 32 * WAVES;    // per-wave K/V split work of a 4-wave block (
 constexpr int NT = 64 * WAVES;
 constexpr int KST = 72;   // K plane row stride (halves): 144 B = 9 x 16 B (odd) -> ds_read_b128 rows conflict-free
 constexpr int VST = 96;   // V plane row stride (halves): 192 B -> the 4 rows of a ds_read_b64_tr_b16 block hit disjoint banks
+// + 32 halves: the lo plane starts 16 banks after the hi plane, so the eight lanes that copy one 128-byte planes chunk
+// (4 hi pieces + 4 lo pieces) into LDS hit 32 different store banks (without it: a 2-way conflict on every ds_write_b128)
+#ifdef ATTN_NO_PLANE_PAD
 constexpr int K_PLANE = KT * KST, V_PLANE = KT * VST;
+#else
+constexpr int K_PLANE = KT * KST + 32, V_PLANE = KT * VST + 32;
+#endif
 constexpr size_t X3_ATTN_STAGE_BYTES = size_t(2) * (K_PLANE + V_PLANE) * sizeof(_Float16);  // 43 008 B
 constexpr int OST = 68;   // epilogue staging row (floats)
 constexpr size_t X3_ATTN_EPI_BYTES = size_t(32) * 8 * OST * sizeof(float);  // O^T transpose staging, 32 rows per wave

@@ -217,7 +217,7 @@ class DinoVisionTransformer(nn.Module):
         return ws
 
     # ---- forward --------------------------------------------------------------------------
-    def _run(self, x, taps=()):
+    def _run(self, x, taps=(), out_norm=None):
         require_cuda(x, "DinoVisionTransformer.forward")
         require_cuda(self.cls_token, "DinoVisionTransformer weights")
         if x.dtype != torch.float32:
@@ -235,7 +235,13 @@ class DinoVisionTransformer(nn.Module):
         nbytes = L.pope_vit_workspace_bytes(B, ntok, dim, w.hidden)
         ws = self._workspace(nbytes, x.device)
         x_pre = torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32)
-        x_norm = torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32)
+        if out_norm is None:
+            x_norm = torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32)
+        else:  # caller-provided destination (a batch slice of a larger buffer: no concatenation afterwards)
+            if out_norm.shape != (B, ntok, dim) or out_norm.dtype != torch.float32 or not out_norm.is_contiguous() \
+                    or out_norm.device != x.device:
+                raise ValueError("out_norm must be a contiguous float32 [B, ntok, dim] tensor on the input's device")
+            x_norm = out_norm
         tap_out = [torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32) for _ in taps]
         tap_blocks = (C.c_int * max(1, len(taps)))(*taps)
         tap_ptrs = (C.c_void_p * max(1, len(taps)))(*[t.data_ptr() for t in tap_out])
@@ -265,12 +271,13 @@ class DinoVisionTransformer(nn.Module):
         return ops.patch_embed(x, self.patch_embed.proj.weight.detach(), self._posb(H, W, ntok), self.patch_size,
                                precision=self.precision)
 
-    def forward_features(self, x, masks=None):
+    def forward_features(self, x, masks=None, out_norm=None):
+        """`out_norm` (extension): preallocated [B, ntok, dim] buffer that receives the final-norm tokens."""
         if isinstance(x, list):
             raise NotImplementedError("pope_amd: nested-tensor (list) inputs are a training-time xformers path")
         if masks is not None:
             raise NotImplementedError("pope_amd: iBOT mask tokens are training-only (out of the hot path)")
-        x_pre, x_norm, _ = self._run(x)
+        x_pre, x_norm, _ = self._run(x, out_norm=out_norm)
         return {"x_norm_clstoken": x_norm[:, 0], "x_norm_patchtokens": x_norm[:, 1:],
                 "x_prenorm": x_pre, "masks": masks}
 

@@ -53,24 +53,25 @@ class PairPipeline:
         With streams > 1 consecutive chunks run on different HIP streams (own scratch each), so the
         HBM-bound kernels and the tile-quantisation tails of one chunk overlap the MFMA phases of another."""
         starts = list(range(0, images.shape[0], self.chunk))
+        B, _, H, W = images.shape
+        p = self.model.patch_size
+        # every chunk writes its normalised tokens straight into its slice of one buffer: no concatenation pass
+        tokens = torch.empty(B, 1 + (H // p) * (W // p), self.model.embed_dim, device=images.device, dtype=torch.float32)
         if self.n_streams <= 1 or len(starts) == 1:
-            outs = [self.model(images[s:s + self.chunk], is_training=True)["x_norm_patchtokens"] for s in starts]
-            return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+            for s in starts:
+                self.model(images[s:s + self.chunk], is_training=True, out_norm=tokens[s:s + self.chunk])
+            return tokens[:, 1:]
         main = torch.cuda.current_stream(images.device)
         if self._streams is None:
             self._streams = [torch.cuda.Stream(images.device) for _ in range(self.n_streams)]
-        outs = []
         for st in self._streams:
             st.wait_stream(main)
         for k, s in enumerate(starts):
-            st = self._streams[k % self.n_streams]
-            with torch.cuda.stream(st):
-                o = self.model(images[s:s + self.chunk], is_training=True)["x_norm_patchtokens"]
-            o.record_stream(main)
-            outs.append(o)
+            with torch.cuda.stream(self._streams[k % self.n_streams]):
+                self.model(images[s:s + self.chunk], is_training=True, out_norm=tokens[s:s + self.chunk])
         for st in self._streams:
             main.wait_stream(st)
-        return torch.cat(outs, 0)
+        return tokens[:, 1:]
 
     @torch.no_grad()
     def __call__(self, img0, img1):
