@@ -439,7 +439,11 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         return cat(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, c));
     };
 
-    f32x16 o0, o1, c0, c1, n0, n1;  // output accumulators; scores / probabilities of tile t; scores of tile t+1
+    // output accumulators; two score buffers that swap roles every tile (P = parity of the tile whose probabilities a
+    // buffer holds): sb[P] = scores / probabilities of tile t, sb[P ^ 1] = scores of tile t + 1 — no copies
+    f32x16 o0, o1, sb[2][2];
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
     float m_run = -INFINITY;
@@ -473,7 +477,9 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     // are rescaled unconditionally (alpha == 1 exactly when the row maximum did not move): no branch in the phase.
     float sm_mt = 0.f, sm_alpha = 0.f, sm_shift = 0.f;
     f32x2 sm_ls = {0.f, 0.f};
-    auto softmax_slice = [&](int slot) {
+    auto softmax_slice = [&](int slot, auto ptag) {
+        f32x16& c0 = sb[decltype(ptag)::value][0];
+        f32x16& c1 = sb[decltype(ptag)::value][1];
         if (slot == 0) {
             sm_mt = vmax3(c0[0], c1[0], c0[1]);
 #pragma unroll
@@ -507,7 +513,9 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         }
     };
     // ---- phase 1: S^T(tile in stage st_next) -> (n0, n1), each MFMA followed by a slice of the softmax of (c0, c1)
-    auto phase1 = [&](int st_next) {
+    auto phase1 = [&](int st_next, auto ptag) {
+        f32x16& n0 = sb[decltype(ptag)::value ^ 1][0];
+        f32x16& n1 = sb[decltype(ptag)::value ^ 1][1];
         KFrag kf[2];
         read_kfrag(st_next, 0, kf[0]);
 #pragma unroll
@@ -517,31 +525,33 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
             const int kg = i / 6, j = i % 6;
             if (j == 0 && kg < 3) read_kfrag(st_next, kg + 1, kf[(kg + 1) & 1]);
             qk_step(kg, j, kf[kg & 1], n0, n1);
-            softmax_slice(i);
+            softmax_slice(i, ptag);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto softmax_only = [&]() {
+    auto softmax_only = [&](auto ptag) {
 #pragma unroll
-        for (int i = 0; i < 24; ++i) softmax_slice(i);
+        for (int i = 0; i < 24; ++i) softmax_slice(i, ptag);
     };
     // ---- phase 2: O^T += V^T(stage st) . P^T with P = (c0, c1); the hi/lo split of the next 16 keys' probabilities
     // (and, SPLIT_KV, of one K/V row of tile t+2 per group) sits behind the MFMAs of the current 16 keys
-    auto split_group = [&](int g, int half, f16x4& hi, f16x4& lo) {
+    auto split_group = [&](int g, int half, f16x4& hi, f16x4& lo, auto ptag) {
+        const f32x16& c0 = sb[decltype(ptag)::value][0];
+        const f32x16& c1 = sb[decltype(ptag)::value][1];
         const int u = g >> 1, s2 = g & 1;
         f32x4 pv4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) pv4[e] = (u ? c1 : c0)[8 * s2 + 4 * half + e];
         split4(pv4, hi, lo);
     };
-    auto phase2 = [&](int st, int st_write, auto split_tag, const u32x4 (&pregs)[4]) {
+    auto phase2 = [&](int st, int st_write, auto split_tag, const u32x4 (&pregs)[4], auto ptag) {
         constexpr bool SPLIT_KV = decltype(split_tag)::value;
         const _Float16* Vh = lds + st * STAGE_H + 2 * K_PLANE;
         const _Float16* Vl = Vh + V_PLANE;
         f16x4 h0[2], l0[2], h1[2], l1[2];
         f16x8 vf[2][4];
-        split_group(0, 0, h0[0], l0[0]);
-        split_group(0, 1, h1[0], l1[0]);
+        split_group(0, 0, h0[0], l0[0], ptag);
+        split_group(0, 1, h1[0], l1[0], ptag);
         vf[0][0] = vfrag(Vh, 0, 0, 0); vf[0][1] = vfrag(Vl, 0, 0, 0);
         vf[0][2] = vfrag(Vh, 0, 0, 1); vf[0][3] = vfrag(Vl, 0, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -561,8 +571,8 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
             if (j == 4) o0 = mfma_f16(vf[cur][0], ph, o0);
             if (j == 5) o1 = mfma_f16(vf[cur][2], ph, o1);
             if (g < 3) {
-                if (j == 1) split_group(g + 1, 0, h0[nxt], l0[nxt]);
-                if (j == 3) split_group(g + 1, 1, h1[nxt], l1[nxt]);
+                if (j == 1) split_group(g + 1, 0, h0[nxt], l0[nxt], ptag);
+                if (j == 3) split_group(g + 1, 1, h1[nxt], l1[nxt], ptag);
             }
             if (SPLIT_KV && j == 5) {  // a quarter of tile t+2's staging per 16-key group
                 if constexpr (IN_PLANES) {
@@ -595,15 +605,15 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     {
         KFrag kf;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { sb[0][0][i] = 0.f; sb[0][1][i] = 0.f; }
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             read_kfrag(0, kg, kf);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) qk_step(kg, j, kf, c0, c1);
+            for (int j = 0; j < 6; ++j) qk_step(kg, j, kf, sb[0][0], sb[0][1]);
         }
     }
-    if (nkt == 1) mask_tail(0, c0, c1);
+    if (nkt == 1) mask_tail(0, sb[0][0], sb[0][1]);
     if constexpr (IN_PLANES) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) write_chunk(1, c, pb);
@@ -614,43 +624,50 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         if (nkt > 2) load_kv(2);
     }
     __syncthreads();
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c0), "+v"(c1));  // XDL write -> asm VALU read (vmax3) wait states
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sb[0][0]), "+v"(sb[0][1]));  // XDL write -> asm VALU read (vmax3) wait states
 
     // stage of tile t = t % 3
     int st_cur = 0, st_next = 1, st_write = 2, t = 0;
     auto rotate = [&]() { const int x = st_cur; st_cur = st_next; st_next = st_write; st_write = x; };
-    // one steady-state iteration (tiles t+1 and t+2 exist); `regs` holds tile t+2 and is refilled with tile t+4
-    auto steady = [&](u32x4 (&regs)[4]) {
+    // one steady-state iteration (tiles t+1 and t+2 exist); `regs` holds tile t+2 and is refilled with tile t+4;
+    // ptag = parity of t = the score buffer that holds tile t
+    auto steady = [&](u32x4 (&regs)[4], auto ptag) {
         ATTN_STAMP(t, 0);
-        phase1(st_next);
+        phase1(st_next, ptag);
         ATTN_STAMP(t, 1);
-        phase2(st_cur, st_write, std::true_type{}, regs);  // also moves tile t+2 from registers into stage st_write
+        phase2(st_cur, st_write, std::true_type{}, regs, ptag);  // also moves tile t+2 from registers into stage st_write
         if constexpr (IN_PLANES) load_planes(t + 4, regs);
         else if (t + 3 < nkt) load_kv(t + 3);
         ATTN_STAMP(t, 2);
         __syncthreads();  // tile t+2 is published; every wave is done with stage st_cur
         ATTN_STAMP(t, 3);
-        c0 = n0;
-        c1 = n1;
         rotate();
         ++t;
     };
     while (t + 2 < nkt) {
-        steady(pa);
-        if (t + 2 < nkt) steady(pb);
+        steady(pa, P0{});
+        if (t + 2 < nkt) steady(pb, P1{});
     }
-    if (t + 1 < nkt) {  // second-to-last tile: S^T of the last tile needs the key mask
-        phase1(st_next);
-        mask_tail(t + 1, n0, n1);
-        asm volatile("" : "+v"(n0), "+v"(n1));
-        phase2(st_cur, st_write, std::false_type{}, pa);
-        c0 = n0;
-        c1 = n1;
-        rotate();
-        ++t;
-    }
-    softmax_only();  // last tile
-    phase2(st_cur, st_write, std::false_type{}, pa);
+    // the last one or two tiles; ptag = parity of t
+    auto tail = [&](auto ptag) {
+        constexpr int P = decltype(ptag)::value;
+        using Q = std::integral_constant<int, P ^ 1>;
+        if (t + 1 < nkt) {  // second-to-last tile: S^T of the last tile needs the key mask
+            phase1(st_next, ptag);
+            mask_tail(t + 1, sb[P ^ 1][0], sb[P ^ 1][1]);
+            asm volatile("" : "+v"(sb[P ^ 1][0]), "+v"(sb[P ^ 1][1]));
+            phase2(st_cur, st_write, std::false_type{}, pa, ptag);
+            rotate();
+            ++t;
+            softmax_only(Q{});  // last tile
+            phase2(st_cur, st_write, std::false_type{}, pa, Q{});
+        } else {
+            softmax_only(ptag);
+            phase2(st_cur, st_write, std::false_type{}, pa, ptag);
+        }
+    };
+    if (t & 1) tail(P1{});
+    else tail(P0{});
     __syncthreads();  // the stages are free: reuse them for the O^T transpose
 
     // Normalise (the 2^10 of p' cancels), transpose O^T through LDS, store whole 256-B head rows.
