@@ -57,6 +57,28 @@ __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
 }
 
 __device__ __forceinline__ float gelu_erf_scalar(float x);  // defined below (shared formula with gemm_f32.hip)
+// the same formula on a pair (v_pk_fma_f32 / v_pk_mul_f32 for the polynomial): gemm_f32.hip:gelu_erf2
+__device__ __forceinline__ f32x2 gelu_erf_pair(f32x2 x) {
+    constexpr float P = 0.3275911f * 0.70710678118654752440f;
+    constexpr float A1 = 0.5f * 0.254829592f, A2 = 0.5f * -0.284496736f, A3 = 0.5f * 1.421413741f,
+                    A4 = 0.5f * -1.453152027f, A5 = 0.5f * 1.061405429f;
+    constexpr float NHL2E = -0.5f * 1.44269504088896340736f;
+    f32x2 t, e, relu;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        t[i] = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x[i]), P, 1.0f));
+        relu[i] = __builtin_fmaxf(x[i], 0.0f);
+    }
+    const f32x2 arg = (x * NHL2E) * x;
+    e[0] = __builtin_amdgcn_exp2f(arg[0]);
+    e[1] = __builtin_amdgcn_exp2f(arg[1]);
+    f32x2 poly = __builtin_elementwise_fma(t, f32x2{A5, A5}, f32x2{A4, A4});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{A3, A3});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{A2, A2});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{A1, A1});
+    const f32x2 q = (poly * t) * e;
+    return __builtin_elementwise_fma(relu, __builtin_elementwise_fma(q, f32x2{-2.f, -2.f}, f32x2{1.f, 1.f}), x * q);
+}
 
 // LAB is 0 in the product; scripts/x3_lab.cpp times ablations: bit0 = no global loads after the
 // prologue, bit1 = no split / LDS writes after the first stage, bit2 = no MFMAs.
@@ -421,8 +443,10 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
                         v = v * inv + bias[ni];
                     } else if constexpr (EPI == EPI_BIAS_GELU) {
                         v = v * inv + bias[ni];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_scalar(v[e]);
+                        {
+                            const f32x2 g01 = gelu_erf_pair(f32x2{v[0], v[1]}), g23 = gelu_erf_pair(f32x2{v[2], v[3]});
+                            v = f32x4{g01[0], g01[1], g23[0], g23[1]};
+                        }
                     } else {
                         v = res[i] + v * gamma[ni] + bias[ni];
                     }
@@ -550,8 +574,10 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
                     v = v * inv + bias;
                 } else if constexpr (EPI == EPI_BIAS_GELU) {
                     v = v * inv + bias;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_scalar(v[e]);
+                    {
+                        const f32x2 g01 = gelu_erf_pair(f32x2{v[0], v[1]}), g23 = gelu_erf_pair(f32x2{v[2], v[3]});
+                        v = f32x4{g01[0], g01[1], g23[0], g23[1]};
+                    }
                 } else {
                     v = res[i] + v * gamma + bias;
                 }
