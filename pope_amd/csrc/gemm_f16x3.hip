@@ -645,7 +645,13 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
 #else
         read_frags(s & 1, 0, f0);
 #endif
-#ifndef X3_NO_STAGE  // dev timing experiment (wrong results): no staging work in the loop
+#if defined(X3_NO_DSWRITE)   // dev timing experiments (wrong results): loads only / LDS stores only / neither
+        load_next(nx);
+        asm volatile("" :: "v"(nx[0]), "v"(nx[NLD - 1]));
+#elif defined(X3_NO_LOAD)
+        write_stage((s + 1) & 1, nx);
+        if (++ld_kt == nk) { ld_kt = 0; ld_tile = tile_of(++ld_ord); }
+#elif !defined(X3_NO_STAGE)
         write_stage((s + 1) & 1, nx);
         load_next(nx);
 #else
