@@ -1,0 +1,157 @@
+// Dev lab: the f16x3 GEMM K-step with (A) register staging (buffer_load -> VGPR -> ds_write_b128, padded rows, 2 LDS
+// stages) versus (B) loads straight into LDS (buffer_load ... lds, unpadded XOR-swizzled rows, 3 LDS stages).  Timing
+// only (no results are checked): same loads, fragment reads and 24 MFMAs per K-step and wave in both variants.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+constexpr int NK = 12;  // K-steps per tile
+
+template <int MODE>  // 0: register staging, 1: LDS-DMA
+__device__ __forceinline__ void body(const float* A, const float* W, float* out, int tiles_per_wg, int n_rows_a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* lds = reinterpret_cast<_Float16*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    constexpr int ROWH = MODE ? 64 : 72;              // halves per LDS row (128 B unpadded / 144 B padded)
+    constexpr int STAGE = 256 * ROWH;                 // A 128 rows + W 128 rows
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, unsigned(n_rows_a) * 1536u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 1152u * 1536u, 0x00020000);
+    f32x16 acc[4] = {};
+    // fragment read offsets (halves)
+    int a_off[2][4], w_off[2][4];  // [t][kg*2 + plane]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ra_ = wm * 64 + t * 32 + r, rw_ = 128 + wn * 64 + t * 32 + r;
+            const int p = 2 * (q >> 1) + h + 4 * (q & 1);
+            if (MODE) {
+                a_off[t][q] = ra_ * ROWH + ((p ^ ((ra_ >> 1) & 7)) * 8);
+                w_off[t][q] = rw_ * ROWH + ((p ^ ((rw_ >> 1) & 7)) * 8);
+            } else {
+                a_off[t][q] = ra_ * ROWH + p * 8;
+                w_off[t][q] = rw_ * ROWH + p * 8;
+            }
+        }
+    u32x4 s0[8], s1[8];
+    const int slot = tid >> 3, pc = tid & 7;
+    int tile = blockIdx.x * tiles_per_wg, kt = 0;
+    auto voff_a = [&](int i) -> unsigned {
+        if (MODE) { const int row = wave * 32 + i * 8 + (lane >> 3); return unsigned(tile * 128 + row) * 1536u + unsigned(((lane & 7) ^ ((row >> 1) & 7)) * 16); }
+        return unsigned(tile * 128 + slot + 32 * i) * 1536u + pc * 16u;
+    };
+    auto voff_w = [&](int i) -> unsigned {
+        const int n0 = (tile % 9) * 128;
+        if (MODE) { const int row = wave * 32 + i * 8 + (lane >> 3); return unsigned(n0 + row) * 1536u + unsigned(((lane & 7) ^ ((row >> 1) & 7)) * 16); }
+        return unsigned(n0 + slot + 32 * i) * 1536u + pc * 16u;
+    };
+    auto advance = [&]() { if (++kt == NK) { kt = 0; ++tile; } };
+    auto load_regs = [&](u32x4 (&st)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            st[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a(i), kt * 128, 0);
+            st[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w(i), kt * 128, 0);
+        }
+        advance();
+    };
+    auto load_dma = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            _Float16* da = lds + stage * STAGE + (wave * 32 + i * 8) * ROWH;
+            _Float16* dw = da + 128 * ROWH;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)da, 16, voff_a(i), kt * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)dw, 16, voff_w(i), kt * 128, 0, 0);
+        }
+        advance();
+    };
+    auto write_regs = [&](int stage, const u32x4 (&st)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(lds + stage * STAGE + (slot + 32 * i) * ROWH + pc * 8) = st[i];
+            *reinterpret_cast<u32x4*>(lds + stage * STAGE + (128 + slot + 32 * i) * ROWH + pc * 8) = st[4 + i];
+        }
+    };
+    auto compute = [&](int stage) {
+        const _Float16* S = lds + stage * STAGE;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            f16x8 ah[2], al[2], wh[2], wl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const f16x8*>(S + a_off[t][kg * 2]);
+                al[t] = *reinterpret_cast<const f16x8*>(S + a_off[t][kg * 2 + 1]);
+                wh[t] = *reinterpret_cast<const f16x8*>(S + w_off[t][kg * 2]);
+                wl[t] = *reinterpret_cast<const f16x8*>(S + w_off[t][kg * 2 + 1]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    f32x16& c = acc[mi * 2 + ni];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ni], ah[mi], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ni], al[mi], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ni], ah[mi], c, 0, 0, 0);
+                }
+        }
+    };
+    const int n_items = tiles_per_wg * NK;
+    if (MODE == 0) {
+        load_regs(s0); write_regs(0, s0); load_regs(s1); load_regs(s0);
+        __syncthreads();
+        for (int s = 0; s < n_items; s += 2) {
+            write_regs(1, s1); load_regs(s1); compute(0); __syncthreads();
+            write_regs(0, s0); load_regs(s0); compute(1); __syncthreads();
+        }
+    } else {
+        load_dma(0); load_dma(1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __syncthreads();
+        for (int s = 0; s < n_items; s += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                load_dma((u + 2) % 3);                               // item s+u+2
+                compute(u);                                          // item s+u
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // item s+u+1 has landed (this item's 8 may fly)
+                __syncthreads();
+            }
+        }
+    }
+    float sum = 0.f;
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) sum += acc[i][e];
+    if (sum == 1234.5f) out[tid] = sum;
+}
+
+__global__ __launch_bounds__(256, 2) void k_reg(const float* A, const float* W, float* out, int t, int n) { body<0>(A, W, out, t, n); }
+__global__ __launch_bounds__(256, 2) void k_dma(const float* A, const float* W, float* out, int t, int n) { body<1>(A, W, out, t, n); }
+
+template <int MODE>
+void run(const char* name, const float* A, const float* W, float* out, int wgs, size_t lds, int n_rows) {
+    auto kern = MODE ? k_dma : k_reg;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    const int tiles_per_wg = 12 * 512 / wgs;   // same total work
+    float best = 1e9;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a); hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds, 0, A, W, out, tiles_per_wg, n_rows); hipEventRecord(b);
+        hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+    }
+    const double items = double(wgs) * tiles_per_wg * NK;
+    printf("%-44s %4d WGs: %.3f ms  -> %.0f ns per K-step per CU-slot, %.0f TF/s executed\n", name, wgs, best,
+           best * 1e6 / (items / wgs), items * 4 * 24 * 32768.0 / (best * 1e-3) / 1e12);
+}
+
+int main() {
+    const int n_rows = 512 * 12 * 128 + 256;
+    float *A, *W, *out;
+    hipMalloc(&A, size_t(n_rows) * 1536); hipMalloc(&W, 1152 * 1536); hipMalloc(&out, 4096);
+    hipMemset(A, 0, size_t(n_rows) * 1536); hipMemset(W, 0, 1152 * 1536);
+    for (int r = 0; r < 2; ++r) {
+        run<0>("register staging, 2 stages, 2 WG/CU", A, W, out, 512, 2 * 256 * 72 * 2, n_rows);
+        run<0>("register staging, 2 stages, 1 WG/CU", A, W, out, 256, 100000, n_rows);
+        run<1>("LDS-DMA, 3 stages, 1 WG/CU", A, W, out, 256, 3 * 256 * 64 * 2, n_rows);
+    }
+    return 0;
+}
