@@ -124,14 +124,76 @@ __device__ __forceinline__ void body(const float* A, const float* W, float* out,
     if (sum == 1234.5f) out[tid] = sum;
 }
 
+// Variant C: half K-steps (16 instead of 32): 20 KB LDS stages, half the staging registers -> three workgroups per CU.
+__device__ __forceinline__ void body_k16(const float* A, const float* W, float* out, int tiles_per_wg, int n_rows_a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* lds = reinterpret_cast<_Float16*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    constexpr int ROWH = 40;                 // 16 hi + 16 lo halves + 16 B pad
+    constexpr int STAGE = 256 * ROWH;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, unsigned(n_rows_a) * 1536u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 1152u * 1536u, 0x00020000);
+    f32x16 acc[4] = {};
+    u32x4 s0[4], s1[4];
+    const int slot = tid >> 2, pc = tid & 3;   // 4 lanes per row: hi p0, hi p1, lo p0, lo p1
+    int tile = blockIdx.x * tiles_per_wg, kt = 0;
+    auto load_regs = [&](u32x4 (&st)[4]) {
+        const unsigned col = unsigned((kt >> 1) * 128 + (kt & 1) * 32 + (pc >> 1) * 64 + (pc & 1) * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            st[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, unsigned(tile * 128 + slot + 64 * i) * 1536u + col, 0, 0);
+            st[2 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, unsigned((tile % 9) * 128 + slot + 64 * i) * 1536u + col, 0, 0);
+        }
+        if (++kt == 2 * NK) { kt = 0; ++tile; }
+    };
+    auto write_regs = [&](int stage, const u32x4 (&st)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<u32x4*>(lds + stage * STAGE + (slot + 64 * i) * ROWH + pc * 8) = st[i];
+            *reinterpret_cast<u32x4*>(lds + stage * STAGE + (128 + slot + 64 * i) * ROWH + pc * 8) = st[2 + i];
+        }
+    };
+    auto compute = [&](int stage) {
+        const _Float16* S = lds + stage * STAGE;
+        f16x8 ah[2], al[2], wh[2], wl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            ah[t] = *reinterpret_cast<const f16x8*>(S + (wm * 64 + t * 32 + r) * ROWH + 8 * h);
+            al[t] = *reinterpret_cast<const f16x8*>(S + (wm * 64 + t * 32 + r) * ROWH + 16 + 8 * h);
+            wh[t] = *reinterpret_cast<const f16x8*>(S + (128 + wn * 64 + t * 32 + r) * ROWH + 8 * h);
+            wl[t] = *reinterpret_cast<const f16x8*>(S + (128 + wn * 64 + t * 32 + r) * ROWH + 16 + 8 * h);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                f32x16& c = acc[mi * 2 + ni];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ni], ah[mi], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ni], al[mi], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ni], ah[mi], c, 0, 0, 0);
+            }
+    };
+    const int n_items = tiles_per_wg * NK * 2;
+    load_regs(s0); write_regs(0, s0); load_regs(s1); load_regs(s0);
+    __syncthreads();
+    for (int s = 0; s < n_items; s += 2) {
+        write_regs(1, s1); load_regs(s1); compute(0); __syncthreads();
+        write_regs(0, s0); load_regs(s0); compute(1); __syncthreads();
+    }
+    float sum = 0.f;
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) sum += acc[i][e];
+    if (sum == 1234.5f) out[tid] = sum;
+}
+__global__ __launch_bounds__(256, 3) void k_k16(const float* A, const float* W, float* out, int t, int n) { body_k16(A, W, out, t, n); }
+
 __global__ __launch_bounds__(256, 2) void k_reg(const float* A, const float* W, float* out, int t, int n) { body<0>(A, W, out, t, n); }
 __global__ __launch_bounds__(256, 2) void k_dma(const float* A, const float* W, float* out, int t, int n) { body<1>(A, W, out, t, n); }
 
 template <int MODE>
 void run(const char* name, const float* A, const float* W, float* out, int wgs, size_t lds, int n_rows) {
-    auto kern = MODE ? k_dma : k_reg;
+    auto kern = MODE == 2 ? k_k16 : MODE ? k_dma : k_reg;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    const int tiles_per_wg = 12 * 512 / wgs;   // same total work
+    const int tiles_per_wg = 12 * 1536 / wgs;   // same total work
     float best = 1e9;
     for (int rep = 0; rep < 4; ++rep) {
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -139,12 +201,11 @@ void run(const char* name, const float* A, const float* W, float* out, int wgs, 
         hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
     }
     const double items = double(wgs) * tiles_per_wg * NK;
-    printf("%-44s %4d WGs: %.3f ms  -> %.0f ns per K-step per CU-slot, %.0f TF/s executed\n", name, wgs, best,
-           best * 1e6 / (items / wgs), items * 4 * 24 * 32768.0 / (best * 1e-3) / 1e12);
+    printf("%-44s %4d WGs: %.3f ms  -> %.0f TF/s executed\n", name, wgs, best, items * 4 * 24 * 32768.0 / (best * 1e-3) / 1e12);
 }
 
 int main() {
-    const int n_rows = 512 * 12 * 128 + 256;
+    const int n_rows = 1536 * 12 * 128 + 256;
     float *A, *W, *out;
     hipMalloc(&A, size_t(n_rows) * 1536); hipMalloc(&W, 1152 * 1536); hipMalloc(&out, 4096);
     hipMemset(A, 0, size_t(n_rows) * 1536); hipMemset(W, 0, 1152 * 1536);
@@ -152,6 +213,8 @@ int main() {
         run<0>("register staging, 2 stages, 2 WG/CU", A, W, out, 512, 2 * 256 * 72 * 2, n_rows);
         run<0>("register staging, 2 stages, 1 WG/CU", A, W, out, 256, 100000, n_rows);
         run<1>("LDS-DMA, 3 stages, 1 WG/CU", A, W, out, 256, 3 * 256 * 64 * 2, n_rows);
+        run<2>("register staging, K16 steps, 3 WG/CU", A, W, out, 768, 2 * 256 * 40 * 2, n_rows);
+        run<2>("register staging, K16 steps, 2 WG/CU", A, W, out, 512, 70000, n_rows);
     }
     return 0;
 }
