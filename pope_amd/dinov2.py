@@ -229,6 +229,21 @@ class DinoVisionTransformer(nn.Module):
         assert W % p == 0, f"Input image width {W} is not a multiple of patch width: {p}"
         ntok = 1 + (H // p) * (W // p)
         dim = self.embed_dim
+        # The kernels address a launch sequence's activations through 32-bit byte offsets: larger batches are run as
+        # several sequences writing into slices of the same outputs (identical results: images are independent).
+        widest = max(4 * dim, int(self.blocks[0].mlp.fc1.weight.shape[0]))
+        max_b = max(1, ((1 << 32) - (1 << 20)) // ((ntok * widest + 256 * widest) * 4))
+        max_b = min(max_b, getattr(self, "_max_batch", None) or max_b)   # test hook
+        if B > max_b:
+            x_pre = torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32)
+            x_norm = out_norm if out_norm is not None else torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32)
+            tap_out = [torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32) for _ in taps]
+            for s in range(0, B, max_b):
+                pre_s, _, taps_s = self._run(x[s:s + max_b], taps, out_norm=x_norm[s:s + max_b])
+                x_pre[s:s + max_b] = pre_s
+                for dst, src in zip(tap_out, taps_s):
+                    dst[s:s + max_b] = src
+            return x_pre, x_norm, tap_out
         w = self._weights()
         posb = self._posb(H, W, ntok)
         L = _lib.lib()

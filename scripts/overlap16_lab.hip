@@ -78,6 +78,46 @@ __global__ __launch_bounds__(256) void ki(float* out, int iters) {
     if (s == 1234.5678f) out[threadIdx.x] = s;
 }
 
+// In-wave interleave with ONLY transcendental ops (v_exp_f32) or ONLY fma behind each MFMA: cost per op.
+template <int PER, int TRANS>
+__global__ __launch_bounds__(256) void kt(float* out, int iters) {
+    f32x16 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+    f16x8 x, y;
+    for (int i = 0; i < 8; ++i) { x[i] = _Float16(threadIdx.x * 1e-3f + i); y[i] = _Float16(blockIdx.x * 1e-4f - i); }
+    float z[8];
+    for (int i = 0; i < 8; ++i) z[i] = threadIdx.x * 1e-3f + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+            if ((j & 3) == 0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a0, 0, 0, 0);
+            if ((j & 3) == 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, a1, 0, 0, 0);
+            if ((j & 3) == 2) a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, x, a2, 0, 0, 0);
+            if ((j & 3) == 3) a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, y, a3, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < PER; ++v) {
+                if (TRANS) z[v & 7] = __builtin_amdgcn_exp2f(z[v & 7]);
+                else z[v & 7] = __builtin_fmaf(z[v & 7], 0.9999f, 0.25f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += z[i];
+    for (int i = 0; i < 16; ++i) s += a0[i] + a1[i] + a2[i] + a3[i];
+    if (s == 1234.5678f) out[threadIdx.x] = s;
+}
+template <int PER, int TRANS>
+void runt(const char* name, float* out) {
+    const int iters = 400;
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a); hipLaunchKernelGGL((kt<PER, TRANS>), dim3(512), dim3(256), 0, 0, out, iters); hipEventRecord(b);
+        hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+    }
+    printf("%-34s 2 waves/SIMD: %7.1f ns per 24-MFMA iteration per wave (%d ops per MFMA)\n", name, best * 1e6 / iters / 2, PER);
+}
+
 template <int NM, int NV>
 void runi(const char* name, float* out) {
     const int iters = 400;
@@ -124,6 +164,12 @@ int main() {
         runi<24, 96>("interleaved 24 MFMA + 96 VALU", out);
         runi<24, 192>("interleaved 24 MFMA + 192 VALU", out);
         runi<24, 288>("interleaved 24 MFMA + 288 VALU", out);
+        runt<0, 0>("MFMA only", out);
+        runt<4, 0>("4 v_fma per MFMA", out);
+        runt<8, 0>("8 v_fma per MFMA", out);
+        runt<2, 1>("2 v_exp per MFMA", out);
+        runt<4, 1>("4 v_exp per MFMA", out);
+        runt<8, 1>("8 v_exp per MFMA", out);
     }
     return 0;
 }

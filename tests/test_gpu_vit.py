@@ -69,6 +69,27 @@ def test_batch_invariance_and_determinism(model):
     assert torch.equal(a, c)
 
 
+def test_oversized_batch_is_split_transparently(model):
+    """Batches beyond the kernels' 32-bit addressing are run as several launch sequences (forced here with a tiny
+    limit): outputs, taps and caller-provided output buffers are bit-identical to the single-sequence run."""
+    from pope_amd import synth
+    x = synth.synthetic_images(5, 56, 70, seed=4).to(model.cls_token.device)
+    ref = model(x, is_training=True)
+    ref_taps = model.get_intermediate_layers(x, n=2, norm=False)
+    model._max_batch = 2
+    try:
+        out = model(x, is_training=True)
+        taps = model.get_intermediate_layers(x, n=2, norm=False)
+        buf = torch.empty_like(ref["x_prenorm"])
+        out2 = model(x, is_training=True, out_norm=buf)
+    finally:
+        model._max_batch = None
+    for k in ("x_norm_clstoken", "x_norm_patchtokens", "x_prenorm"):
+        assert torch.equal(out[k], ref[k]), k
+    assert all(torch.equal(a, b) for a, b in zip(taps, ref_taps))
+    assert out2["x_norm_patchtokens"].data_ptr() == buf[:, 1:].data_ptr() and torch.equal(buf[:, 0], ref["x_norm_clstoken"])
+
+
 def test_full_size_properties(model):
     # BASELINE shape (476x630, N=1531) at a batch the oracle cannot follow in seconds: check
     # size-independent properties — LayerNorm'd tokens have the affine-transformed unit statistics,
