@@ -124,6 +124,73 @@ __device__ __forceinline__ void body(const float* A, const float* W, float* out,
     if (sum == 1234.5f) out[tid] = sum;
 }
 
+// Variant D: W fragments straight from global/L2 into registers in MFMA layout (W never touches LDS): half the LDS
+// stores and fragment reads, 50 % more (and less coalesced) vector-memory traffic.
+__device__ __forceinline__ void body_wdirect(const float* A, const float* W, float* out, int tiles_per_wg, int n_rows_a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* lds = reinterpret_cast<_Float16*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    constexpr int ROWH = 72, STAGE = 128 * ROWH;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, unsigned(n_rows_a) * 1536u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 1152u * 1536u, 0x00020000);
+    f32x16 acc[4] = {};
+    u32x4 s0[4], s1[4];          // A staging
+    u32x4 w0[8], w1[8];          // W fragments of two K-steps: [t][kg][plane]
+    const int slot = tid >> 3, pc = tid & 7;
+    int tile = blockIdx.x * tiles_per_wg, kt = 0;
+    auto load = [&](u32x4 (&st)[4], u32x4 (&wf)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            st[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, unsigned(tile * 128 + slot + 32 * i) * 1536u + pc * 16u, kt * 128, 0);
+        const int n0 = (tile % 9) * 128;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)   // q = kg*2 + plane: piece 2kg + h (+4 for lo)
+                wf[t * 4 + q] = __builtin_amdgcn_raw_buffer_load_b128(
+                    rw, unsigned(n0 + wn * 64 + t * 32 + r) * 1536u + unsigned((2 * (q >> 1) + h + 4 * (q & 1)) * 16), kt * 128, 0);
+        if (++kt == NK) { kt = 0; ++tile; }
+    };
+    auto write_a = [&](int stage, const u32x4 (&st)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(lds + stage * STAGE + (slot + 32 * i) * ROWH + pc * 8) = st[i];
+    };
+    auto compute = [&](int stage, const u32x4 (&wf)[8]) {
+        const _Float16* S = lds + stage * STAGE;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            f16x8 ah[2], al[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const f16x8*>(S + (wm * 64 + t * 32 + r) * ROWH + (2 * kg + h) * 8);
+                al[t] = *reinterpret_cast<const f16x8*>(S + (wm * 64 + t * 32 + r) * ROWH + (2 * kg + h + 4) * 8);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const f16x8 wh = __builtin_bit_cast(f16x8, wf[ni * 4 + kg * 2]), wl = __builtin_bit_cast(f16x8, wf[ni * 4 + kg * 2 + 1]);
+                    f32x16& c = acc[mi * 2 + ni];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah[mi], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al[mi], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah[mi], c, 0, 0, 0);
+                }
+        }
+    };
+    const int n_items = tiles_per_wg * NK;
+    // item s: A stage s&1 (written during item s-1 from regs loaded during item s-2); W frags loaded during item s-1
+    load(s0, w0); write_a(0, s0); load(s1, w1);
+    __syncthreads();
+    for (int s = 0; s < n_items; s += 2) {
+        write_a(1, s1); compute(0, w0); load(s0, w0); __syncthreads();
+        write_a(0, s0); compute(1, w1); load(s1, w1); __syncthreads();
+    }
+    float sum = 0.f;
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) sum += acc[i][e];
+    if (sum == 1234.5f) out[tid] = sum;
+}
+__global__ __launch_bounds__(256, 2) void k_wdirect(const float* A, const float* W, float* out, int t, int n) { body_wdirect(A, W, out, t, n); }
+
 // Variant C: half K-steps (16 instead of 32): 20 KB LDS stages, half the staging registers -> three workgroups per CU.
 __device__ __forceinline__ void body_k16(const float* A, const float* W, float* out, int tiles_per_wg, int n_rows_a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -191,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void k_dma(const float* A, const float* W, 
 
 template <int MODE>
 void run(const char* name, const float* A, const float* W, float* out, int wgs, size_t lds, int n_rows) {
-    auto kern = MODE == 2 ? k_k16 : MODE ? k_dma : k_reg;
+    auto kern = MODE == 3 ? k_wdirect : MODE == 2 ? k_k16 : MODE ? k_dma : k_reg;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     const int tiles_per_wg = 12 * 1536 / wgs;   // same total work
     float best = 1e9;
@@ -215,6 +282,8 @@ int main() {
         run<1>("LDS-DMA, 3 stages, 1 WG/CU", A, W, out, 256, 3 * 256 * 64 * 2, n_rows);
         run<2>("register staging, K16 steps, 3 WG/CU", A, W, out, 768, 2 * 256 * 40 * 2, n_rows);
         run<2>("register staging, K16 steps, 2 WG/CU", A, W, out, 512, 70000, n_rows);
+        run<3>("A via LDS, W fragments direct, 2 WG/CU", A, W, out, 512, 70000, n_rows);
+        run<3>("A via LDS, W fragments direct, 4 WG/CU", A, W, out, 1024, 2 * 128 * 72 * 2, n_rows);
     }
     return 0;
 }
