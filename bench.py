@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the ViT chunks of a step are spread over")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="dev: run the N-rank code path with every rank on cuda:0 and the gloo backend (collectives on "
+                         "CPU copies) — checks the multi-process flow on a 1-GPU box; the numbers mean nothing")
     ap.add_argument("--precision", choices=sorted(PRECISION_INFO), default="f16x3",
                     help="arithmetic of the Linear layers and attention (both are held to the same parity tests)")
     args = ap.parse_args()
@@ -128,10 +131,16 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     import torch.distributed as dist
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_device = torch.device("cpu") if args.rehearse_on_one_gpu else device   # where collective operands live
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
 
     from pope_amd import synth
     from pope_amd.dinov2_utils import load_dinov2_model
@@ -152,7 +161,7 @@ def main():
 
     def step():
         out = pipe(img0, img1)
-        counts = gather_counts(out["counts"].to(device))  # the only exchange: per-pair match counts
+        counts = gather_counts(out["counts"].to(coll_device))  # the only exchange: per-pair match counts
         return out, counts
 
     dominant = "attention"
@@ -191,7 +200,7 @@ def main():
     elapsed = time.perf_counter() - t0
     model.profiler = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
