@@ -81,30 +81,81 @@ __device__ __forceinline__ f32x4 load_w(const GemmParams& g, int row, int k) {
     return *reinterpret_cast<const f32x4*>(g.W + size_t(row) * g.ldw + k);
 }
 
+// Coalesced epilogue through a per-wave 32x68-float LDS transposition (as gemm_core::epilogue_rows), written so that
+// no load sits between two stores: bias / gamma are per-lane constants of the tile and fetched once; the row-indexed
+// operands (residual, patch-embed table) are fetched eight rows at a time before the eight stores; rows >= M and
+// columns >= N are dropped by the buffer descriptor.  (With a load inside each of the 16 row pieces the compiler has to
+// wait for vmcnt(0) — every earlier store acknowledged — before each store: DESIGN.md §4 finding 7.)
 template <int EPI>
 __device__ __forceinline__ void tile_epilogue(const GemmParams& g, int m0, int n0, const f32x16 (&acc)[2][2], float* smem) {
-    // Coalesced epilogue (gemm_core::epilogue_rows): four consecutive output columns per call.
-    epilogue_rows(acc, smem, [&](int tr, int tc, f32x4 v) {
-        const int row = m0 + tr, col = n0 + tc;
-        if (row >= g.M || col >= g.N) return;  // N % 4 == 0: a quad is inside or outside as a whole
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (EPI != EPI_POSB)
-            if (g.bias) bias = *reinterpret_cast<const f32x4*>(g.bias + col);
-        if constexpr (EPI == EPI_BIAS) {
-            v = v + bias;
-        } else if constexpr (EPI == EPI_BIAS_GELU) {
-            v = v + bias;
-            const f32x2 lo = gelu_erf2(f32x2{v[0], v[1]}), hi = gelu_erf2(f32x2{v[2], v[3]});
-            v = f32x4{lo[0], lo[1], hi[0], hi[1]};
-        } else if constexpr (EPI == EPI_BIAS_LS_RES) {
-            const f32x4 gamma = *reinterpret_cast<const f32x4*>(g.gamma + col);
-            const f32x4 res = *reinterpret_cast<const f32x4*>(g.res + size_t(row) * g.ldres + col);
-            v = res + (v + bias) * gamma;
-        } else {  // EPI_POSB: + (pos_embed + conv bias | cls) table indexed by token
-            v = v + *reinterpret_cast<const f32x4*>(g.posb + size_t(row % g.ntok) * g.N + col);
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4e;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    const int c4 = (lane & 15) * 4, lr = lane >> 4;
+    const int col = n0 + wn * 64 + c4;
+    const bool col_ok = col < g.N;
+    const int colc = col_ok ? col : 0;
+    constexpr unsigned DROP = 0xFFFFFF00u;
+    const bool wide = size_t(g.M + BM) * g.ldc * 4 < (size_t(1) << 32) - 512;  // 32-bit buffer offsets cover C
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f}, gamma = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (EPI != EPI_POSB)
+        if (g.bias) bias = *reinterpret_cast<const f32x4*>(g.bias + colc);
+    if constexpr (EPI == EPI_BIAS_LS_RES) gamma = *reinterpret_cast<const f32x4*>(g.gamma + colc);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, wide ? unsigned(g.M) * unsigned(g.ldc) * 4u : 0u, 0x00020000);
+    __syncthreads();  // all waves have finished reading the last K-step stage
+    float* E = smem + wave * 32 * EPI_ST;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g4 + e];
+                *reinterpret_cast<f32x4*>(&E[r * EPI_ST + ni * 32 + 8 * g4 + 4 * h]) = v;
+            }
+        const int row0 = m0 + wm * 64 + mi * 32 + lr;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 extra[4];  // residual / table rows of this half pass (four at a time: the fp32 kernels run at 168 VGPRs)
+            if constexpr (EPI == EPI_BIAS_LS_RES || EPI == EPI_POSB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = row0 + 4 * (4 * half + i);
+                    extra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (row < g.M && col_ok) {
+                        if constexpr (EPI == EPI_BIAS_LS_RES) extra[i] = *reinterpret_cast<const f32x4*>(g.res + size_t(row) * g.ldres + col);
+                        else extra[i] = *reinterpret_cast<const f32x4*>(g.posb + size_t(row % g.ntok) * g.N + col);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * (4 * half + i);
+                f32x4 v = *reinterpret_cast<const f32x4*>(&E[(lr + 4 * (4 * half + i)) * EPI_ST + c4]);
+                if constexpr (EPI == EPI_BIAS) {
+                    v = v + bias;
+                } else if constexpr (EPI == EPI_BIAS_GELU) {
+                    v = v + bias;
+                    const f32x2 lo = gelu_erf2(f32x2{v[0], v[1]}), hi = gelu_erf2(f32x2{v[2], v[3]});
+                    v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                } else if constexpr (EPI == EPI_BIAS_LS_RES) {
+                    v = extra[i] + (v + bias) * gamma;
+                } else {  // EPI_POSB: + (pos_embed + conv bias | cls) table indexed by token
+                    v = v + extra[i];
+                }
+                if (wide) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4e, v), rc,
+                                                           col_ok ? unsigned(row) * unsigned(g.ldc) * 4u + unsigned(col) * 4u : DROP, 0, 0);
+                } else if (row < g.M && col_ok) {
+                    *reinterpret_cast<f32x4*>(g.C + size_t(row) * g.ldc + col) = v;
+                }
+            }
         }
-        *reinterpret_cast<f32x4*>(g.C + size_t(row) * g.ldc + col) = v;
-    });
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 enum { LOAD_GENERIC = 0, LOAD_BUFFER = 1, LOAD_PATCH = 2 };
