@@ -1,0 +1,37 @@
+"""CPU: host-side preprocessing of the drop-in `set_torch_image` (segment_anything/.../dinov2_utils.py:55-78):
+ToPILImage -> Resize((256,256)) -> CenterCrop((196,196)) | Resize((224,224)) -> ToTensor -> Normalize.  torchvision is
+not in this image, so the resize itself (PIL bilinear, what torchvision calls for PIL inputs) is unpinned against the
+reference; geometry, channel handling and normalisation are checked here."""
+import numpy as np
+import torch
+
+from pope_amd import dinov2_utils as du
+from pope_amd.synth import IMAGENET_MEAN, IMAGENET_STD
+
+
+def test_shapes_and_normalisation_of_constant_image():
+    img = np.full((300, 400, 3), (10, 128, 250), np.uint8)   # channels are taken as given (the drivers pass BGR)
+    for crop, hw in ((True, 196), (False, 224)):
+        t = du._prep(img, (256, 256), (196, 196)) if crop else du._prep(img, (224, 224), None)
+        assert t.shape == (3, hw, hw) and t.dtype == torch.float32
+        for c, v in enumerate((10, 128, 250)):
+            want = (v / 255 - IMAGENET_MEAN[c]) / IMAGENET_STD[c]
+            assert torch.allclose(t[c], torch.full_like(t[c], want), atol=1e-6)
+
+
+def test_center_crop_geometry():
+    # 256x256 after resize; crop offsets round((256-196)/2) = 30 on both axes (torchvision CenterCrop)
+    img = np.zeros((256, 256, 3), np.uint8)
+    img[30:226, 30:226] = 255
+    t = du._prep(img, (256, 256), (196, 196))
+    hi = (1.0 - IMAGENET_MEAN[0]) / IMAGENET_STD[0]
+    assert torch.allclose(t[0], torch.full_like(t[0], hi), atol=1e-6)   # exactly the bright square
+
+
+def test_gray_and_tensor_inputs():
+    g = (np.arange(64 * 48).reshape(64, 48) % 256).astype(np.uint8)
+    rgb = np.stack([g, g, g], -1)
+    a, b = du._prep(rgb, (224, 224), None), du._prep(torch.from_numpy(rgb), (224, 224), None)
+    assert torch.equal(a, b)
+    un = a * torch.tensor(IMAGENET_STD).view(3, 1, 1) + torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
+    assert torch.allclose(un[0], un[1], atol=1e-6) and float(un.min()) >= -1e-6 and float(un.max()) <= 1 + 1e-6
