@@ -106,3 +106,26 @@ def test_border_capacity_ties_and_empty(dev):
     f1 = (0.01 * torch.randn(2, 36, 32, generator=g)).to(dev)
     out = dense_match(f0, f1, (6, 6), (6, 6), (48, 48))
     assert len(out["i_ids"]) == 0 and out["mkpts0_c"].shape == (0, 2) and list(out["counts"]) == [0, 0]
+
+
+def test_bench_size_mirror_property(dev, sd0):
+    """Size-independent property at the benchmark's matcher shape (1530 x 1530 x 384 per pair, several pairs per launch):
+    swapping the two images transposes the confidence matrix and mirrors the match list."""
+    from pope_amd.matcher import dense_match
+    g = torch.Generator().manual_seed(11)
+    n, hw, C = 6, (34, 45), 384
+    L = hw[0] * hw[1]
+    f0 = torch.randn(n, L, C, generator=g)
+    perm = torch.stack([torch.randperm(L, generator=g) for _ in range(n)])
+    f1 = torch.gather(f0, 1, perm[..., None].expand(-1, -1, C)) + 0.25 * torch.randn(n, L, C, generator=g)
+    f0, f1 = (3.0 * f0).to(dev), (3.0 * f1).to(dev)
+    a = dense_match(f0, f1, hw, hw, (476, 630))
+    b = dense_match(f1, f0, hw, hw, (476, 630))
+    assert len(a["i_ids"]) > 500 * n // 2
+    np.testing.assert_allclose(a["conf_matrix"].cpu().numpy(), b["conf_matrix"].transpose(1, 2).cpu().numpy(), rtol=2e-5, atol=1e-7)
+    fwd = set(zip(a["b_ids"].tolist(), a["i_ids"].tolist(), a["j_ids"].tolist()))
+    bwd = set(zip(b["b_ids"].tolist(), b["j_ids"].tolist(), b["i_ids"].tolist()))
+    assert fwd == bwd
+    # every reported match is the planted correspondence (interior cells only: border_rm = 2)
+    inv = perm.to(dev)
+    assert bool((inv[a["b_ids"], a["j_ids"]] == a["i_ids"]).all())
