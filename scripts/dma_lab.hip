@@ -3,6 +3,7 @@
 // only (no results are checked): same loads, fragment reads and 24 MFMAs per K-step and wave in both variants.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <vector>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -276,7 +277,17 @@ int main() {
     float *A, *W, *out;
     hipMalloc(&A, size_t(n_rows) * 1536); hipMalloc(&W, 1152 * 1536); hipMalloc(&out, 4096);
     hipMemset(A, 0, size_t(n_rows) * 1536); hipMemset(W, 0, 1152 * 1536);
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < 3; ++r) {
+        if (r == 2) {  // third round: random f16 operands instead of zeros (power / clock effect of toggling data)
+            std::vector<unsigned short> ha(size_t(n_rows) * 768), hw(size_t(1152) * 768);
+            unsigned s = 12345u;
+            auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (unsigned short)(0x3000u | ((s >> 9) & 0x0FFFu) | ((s >> 4) & 0x8000u)); };
+            for (auto& v : ha) v = rnd();
+            for (auto& v : hw) v = rnd();
+            hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
+            hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+            printf("-- random operands --\n");
+        }
         run<0>("register staging, 2 stages, 2 WG/CU", A, W, out, 512, 2 * 256 * 72 * 2, n_rows);
         run<0>("register staging, 2 stages, 1 WG/CU", A, W, out, 256, 100000, n_rows);
         run<1>("LDS-DMA, 3 stages, 1 WG/CU", A, W, out, 256, 3 * 256 * 64 * 2, n_rows);
