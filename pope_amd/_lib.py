@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libpope_hip.so")
+# POPE_LIB_PATH: dev override used by the lab scripts (stamped / ablated builds live outside the tree)
+LIB_PATH = os.environ.get("POPE_LIB_PATH") or os.path.join(_CSRC, "libpope_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -87,6 +88,15 @@ def build(force=False):
     return LIB_PATH
 
 
+def code_object_archs(path=None):
+    """GPU architectures of the code objects bundled in the library, read from the offload-bundle entry ids in the
+    file itself (no extraction: `llvm-objdump --offloading` drops one file per code object next to its input)."""
+    import re
+    with open(path or LIB_PATH, "rb") as f:
+        data = f.read()
+    return sorted({m.decode() for m in re.findall(rb"hipv4-amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", data)})
+
+
 def lib():
     """Load the shared library (once).  Raises if it is missing — there is no CPU fallback."""
     global _lib
@@ -144,6 +154,15 @@ def ptr(t):
 def stream_of(device):
     import torch
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_device_of(t):
+    """Context manager: make `t`'s GPU the current HIP device around a C-ABI call.  torch hands out the NULL handle
+    for every device's default stream, so the stream alone does not name the device (the reference keeps its matcher
+    on cuda:1 while cuda:0 is current, pope_model_api.py:181-184); non-default streams are additionally resolved on
+    the C side (capi.hip:StreamDevice)."""
+    import torch
+    return torch.cuda.device(t.device)
 
 
 def require_cuda(t, what):

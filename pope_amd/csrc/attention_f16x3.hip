@@ -715,24 +715,14 @@ static int launch_attn_x3(const float* qkv, float* out, int B, int N, int heads,
     const dim3 grid(unsigned((N + QB - 1) / QB) * heads * B);
     static const bool pipe = !getenv("POPE_ATTN_NO_PIPE");  // dev switch: the un-pipelined kernel, for A/B runs
     if (pipe) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_pipe_kernel<OUT_PLANES, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(X3_ATTN_PIPE_BYTES)) != hipSuccess)
-                return POPE_ERR_LAUNCH;
-            attr_set = true;
-        }
+        static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
+        if (!pope_opt_in_lds(attn_f16x3_pipe_kernel<OUT_PLANES, false>, X3_ATTN_PIPE_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
         hipLaunchKernelGGL((attn_f16x3_pipe_kernel<OUT_PLANES, false>), grid, dim3(NT), X3_ATTN_PIPE_BYTES, stream, qkv, out, N, heads);
         return pope_check_launch();
     }
     constexpr size_t lds = X3_ATTN_STAGE_BYTES > X3_ATTN_EPI_BYTES ? X3_ATTN_STAGE_BYTES : X3_ATTN_EPI_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_kernel<OUT_PLANES>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
-            return POPE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
+    if (!pope_opt_in_lds(attn_f16x3_kernel<OUT_PLANES>, lds, lds_ok)) return POPE_ERR_LAUNCH;
     hipLaunchKernelGGL(attn_f16x3_kernel<OUT_PLANES>, grid, dim3(NT), lds, stream, qkv, out, N, heads);
     return pope_check_launch();
 }
@@ -751,13 +741,8 @@ int pope_launch_attention_f16x3_planes_io(const void* qkv_planes, void* out_plan
     if ((reinterpret_cast<uintptr_t>(qkv_planes) & 15) || (reinterpret_cast<uintptr_t>(out_planes) & 15)) return POPE_ERR_ARG;
     if (size_t(N) * 3 * heads * HD * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
     const dim3 grid(unsigned((N + QB - 1) / QB) * heads * B);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_pipe_kernel<true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(X3_ATTN_PIPE_BYTES)) != hipSuccess)
-            return POPE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
+    if (!pope_opt_in_lds(attn_f16x3_pipe_kernel<true, true>, X3_ATTN_PIPE_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
     hipLaunchKernelGGL((attn_f16x3_pipe_kernel<true, true>), grid, dim3(NT), X3_ATTN_PIPE_BYTES, stream,
                        static_cast<const float*>(qkv_planes), static_cast<float*>(out_planes), N, heads);
     return pope_check_launch();

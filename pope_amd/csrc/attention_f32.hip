@@ -238,13 +238,8 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
 int pope_launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream) {
     if (B <= 0 || N <= 0 || heads <= 0 || size_t(B) * heads * ((N + QB - 1) / QB) > 0x7fffffffull) return POPE_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return POPE_ERR_ARG;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_kernel<0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ATTN_LDS_BYTES)) != hipSuccess)
-            return POPE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
+    if (!pope_opt_in_lds(attn_f32_kernel<0>, ATTN_LDS_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
     const dim3 grid(unsigned((N + QB - 1) / QB) * heads * B);
     hipLaunchKernelGGL(attn_f32_kernel<0>, grid, dim3(256), ATTN_LDS_BYTES, stream, qkv, out, N, heads);
     return pope_check_launch();

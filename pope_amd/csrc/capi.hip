@@ -8,6 +8,26 @@ namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Every launching entry point runs on the device that owns `stream` (the reference keeps the matcher on cuda:1 while
+// cuda:0 is current, pope_model_api.py:181-184): the launchers' per-device state (LDS opt-in, CU count) and the
+// launches themselves then belong to the right GPU whatever the caller's current device is.  NULL = the current
+// device's default stream.  The previous device is restored on return.
+struct StreamDevice {
+    int prev = -1;
+    bool switched = false;
+    explicit StreamDevice(void* stream) {
+        int dev = -1;
+        if (!stream || hipGetDevice(&prev) != hipSuccess) return;
+        if (hipStreamGetDevice(static_cast<hipStream_t>(stream), &dev) == hipSuccess && dev != prev)
+            switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~StreamDevice() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    StreamDevice(const StreamDevice&) = delete;
+    StreamDevice& operator=(const StreamDevice&) = delete;
+};
+
 // Optional in-situ timing: events[i] is recorded on the stream right before launch i and one more
 // after the last launch, so events[i]..events[i+1] bracket exactly one kernel of the product path.
 // With a kind mask only the selected launches are bracketed: an event is recorded when the coming launch is
@@ -70,6 +90,7 @@ const char* pope_error_string(int code) {
 
 int pope_layernorm_f32(const float* x, const float* weight, const float* bias, float* y, int rows, int dim,
                        float eps, void* stream) {
+    StreamDevice on_device(stream);
     if (!x || !weight || !bias || !y) return POPE_ERR_ARG;
     return pope_launch_layernorm_f32(x, dim, weight, bias, y, dim, rows, dim, eps, static_cast<hipStream_t>(stream));
 }
@@ -81,6 +102,7 @@ int pope_linear_f32(const float* A, const float* W, const float* bias, float* C,
 
 int pope_linear_prec_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
                          int epilogue, const float* gamma, const float* res, int precision, void* stream) {
+    StreamDevice on_device(stream);
     if (!A || !W || !C || epilogue < 0 || epilogue > POPE_EPI_BIAS_LS_RES) return POPE_ERR_ARG;
     if (precision != POPE_PREC_F32_MFMA && precision != POPE_PREC_F16X3) return POPE_ERR_ARG;
     GemmParams g = {};
@@ -96,11 +118,13 @@ int pope_linear_prec_f32(const float* A, const float* W, const float* bias, floa
 }
 
 int pope_split_planes_f32(const float* src, void* planes, int rows, int cols, float scale, void* stream) {
+    StreamDevice on_device(stream);
     return pope_launch_split_planes(src, planes, rows, cols, scale, static_cast<hipStream_t>(stream));
 }
 
 int pope_linear_planes_f32(const void* a_planes, const void* w_planes, const float* bias, float* C, void* c_planes,
                            int M, int N, int K, int epilogue, const float* gamma, const float* res, void* stream) {
+    StreamDevice on_device(stream);
     if (epilogue < 0 || epilogue > POPE_EPI_BIAS_LS_RES) return POPE_ERR_ARG;
     GemmParams g = {};
     g.a_pl = a_planes; g.w_pl = w_planes;
@@ -114,12 +138,14 @@ int pope_linear_planes_f32(const void* a_planes, const void* w_planes, const flo
 
 int pope_layernorm_planes_f32(const float* x, const float* weight, const float* bias, void* y_planes, int rows, int dim,
                               float eps, void* stream) {
+    StreamDevice on_device(stream);
     if (!x || !weight || !bias) return POPE_ERR_ARG;
     return pope_launch_layernorm_planes(x, dim, weight, bias, y_planes, rows, dim, eps, static_cast<hipStream_t>(stream));
 }
 
 int pope_patch_embed_f32(const float* img, const float* proj_w, const float* posb, float* tokens, int B, int H,
                          int W, int patch, int dim, void* stream) {
+    StreamDevice on_device(stream);
     if (!img || !proj_w || !posb || !tokens || B <= 0 || patch <= 0 || H % patch || W % patch) return POPE_ERR_ARG;
     GemmParams g = {};
     g.A = img; g.W = proj_w; g.C = tokens;
@@ -135,6 +161,7 @@ int pope_patch_embed_f32(const float* img, const float* proj_w, const float* pos
 
 int pope_patch_embed_planes_f32(const float* img, const void* proj_w_planes, const float* posb, float* tokens, int B, int H,
                                 int W, int patch, int dim, void* a_planes_scratch, size_t scratch_bytes, void* stream_) {
+    StreamDevice on_device(stream_);
     if (!img || !proj_w_planes || !posb || !tokens || !a_planes_scratch || B <= 0 || patch <= 0 || H % patch || W % patch)
         return POPE_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -154,6 +181,7 @@ int pope_patch_embed_planes_f32(const float* img, const void* proj_w_planes, con
 }
 
 int pope_attention_planes_f32(const void* qkv_planes, void* out_planes, int B, int N, int heads, void* stream) {
+    StreamDevice on_device(stream);
     if (!qkv_planes || !out_planes) return POPE_ERR_ARG;
     return pope_launch_attention_f16x3_planes_io(qkv_planes, out_planes, B, N, heads, static_cast<hipStream_t>(stream));
 }
@@ -163,6 +191,7 @@ int pope_attention_f32(const float* qkv, float* out, int B, int N, int heads, vo
 }
 
 int pope_attention_prec_f32(const float* qkv, float* out, int B, int N, int heads, int precision, void* stream) {
+    StreamDevice on_device(stream);
     if (!qkv || !out) return POPE_ERR_ARG;
     if (precision == POPE_PREC_F16X3) return pope_launch_attention_f16x3(qkv, out, B, N, heads, static_cast<hipStream_t>(stream));
     if (precision != POPE_PREC_F32_MFMA) return POPE_ERR_ARG;
@@ -170,6 +199,7 @@ int pope_attention_prec_f32(const float* qkv, float* out, int B, int N, int head
 }
 
 int pope_cls_cosine_f32(const float* ref, const float* fea, int P, int D, float eps, float* scores, void* stream) {
+    StreamDevice on_device(stream);
     if (!ref || !fea || !scores || P <= 0 || D <= 0) return POPE_ERR_ARG;
     hipLaunchKernelGGL(cls_cosine_kernel, dim3((P + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), ref, fea,
                        P, D, eps, scores);
@@ -187,6 +217,7 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
                             float* x_prenorm, float* x_norm, int n_taps, const int* tap_blocks_host,
                             float* const* tap_out_host, void* workspace, size_t workspace_bytes, void* stream_,
                             Recorder& rec) {
+    StreamDevice on_device(stream_);
     if (!w || !img || !posb || !x_prenorm || !workspace || !w->blocks_host) return POPE_ERR_ARG;
     if (w->dim != w->heads * 64 || w->patch <= 0 || H % w->patch || W % w->patch || B <= 0) return POPE_ERR_ARG;
     if (n_taps < 0 || (n_taps > 0 && (!tap_blocks_host || !tap_out_host))) return POPE_ERR_ARG;
@@ -363,6 +394,7 @@ int pope_dense_match_prec_f32(const float* feat0, long long stride0, const float
                               int S, int C, int h0, int w0, int h1, int w1, float thr, int border_rm, float temperature, float scale, float* conf_matrix,
                               long long* b_ids, long long* i_ids, long long* j_ids, float* mconf, float* mkpts0_c,
                               float* mkpts1_c, int* counts, void* workspace, size_t workspace_bytes, int precision, void* stream) {
+    StreamDevice on_device(stream);
     if (!feat0 || !feat1 || !conf_matrix || !b_ids || !i_ids || !j_ids || !mconf || !mkpts0_c || !mkpts1_c ||
         !counts || !workspace)
         return POPE_ERR_ARG;

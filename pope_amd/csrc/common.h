@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -42,18 +43,40 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return base + (bid >> 3);
 }
 
-// Number of CUs of the current device (cached; 256 on MI355X).  Host-side query, no sync.
+// Per-device host state.  The reference keeps the matcher on cuda:1 and DINOv2 on cuda:0 in one process
+// (pope_model_api.py:181-184), so everything the launchers cache is keyed by the CURRENT device (the Python
+// binding makes the operand's device current around every call).
+constexpr int POPE_MAX_DEVICES = 64;
+static inline int pope_current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= POPE_MAX_DEVICES) d = 0;
+    return d;
+}
+
+// Number of CUs of the current device (cached per device; 256 on MI355X).  Host-side query, no sync.
 static inline int pope_cu_count() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cus = n;
-        else
-            cus = 256;
+    static std::atomic<int> cus[POPE_MAX_DEVICES];
+    const int dev = pope_current_device();
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (!n) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev].store(n, std::memory_order_relaxed);
     }
-    return cus;
+    return n;
+}
+
+// One-time (per kernel AND device) opt-in for more than 64 KB of dynamic LDS.  `done` is a per-kernel bit mask of
+// the devices that already have the attribute.
+typedef std::atomic<unsigned long long> pope_dev_mask;
+template <typename K>
+static inline bool pope_opt_in_lds(K kernel, size_t bytes, pope_dev_mask& done) {
+    const int dev = pope_current_device();
+    if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)) !=
+        hipSuccess)
+        return false;
+    done.fetch_or(1ull << dev, std::memory_order_release);
+    return true;
 }
 
 static inline int pope_check_launch() {

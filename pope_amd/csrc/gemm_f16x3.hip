@@ -715,13 +715,8 @@ __device__ __forceinline__ float gelu_erf_scalar(float x) {
 
 template <int EPI>
 int launch(const GemmParams& g, hipStream_t stream) {
-    static bool attr_set = false;  // 80 KB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f16x3_kernel<EPI>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(X3_LDS_BYTES)) != hipSuccess)
-            return POPE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
+    if (!pope_opt_in_lds(gemm_nt_f16x3_kernel<EPI>, X3_LDS_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     hipLaunchKernelGGL((gemm_nt_f16x3_kernel<EPI>), dim3(tiles), dim3(THREADS), X3_LDS_BYTES, stream, g);
     return pope_check_launch();
@@ -746,13 +741,8 @@ int pope_lab_gemm_f16x3(const GemmParams& g, int lab, hipStream_t stream) {
 template <int EPI, bool OUT_PLANES, int BMT>
 int launch_planes_t(const GemmParams& g, hipStream_t stream, int nbatch = 1) {
     constexpr size_t lds = size_t(2) * (BMT + BN) * ROW2 * sizeof(_Float16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f16x3_planes_kernel<EPI, OUT_PLANES, BMT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
-            return POPE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
+    if (!pope_opt_in_lds(gemm_nt_f16x3_planes_kernel<EPI, OUT_PLANES, BMT>, lds, lds_ok)) return POPE_ERR_LAUNCH;
     const int tiles = nbatch * ((g.M + BMT - 1) / BMT) * ((g.N + BN - 1) / BN);
     // 128-row tiles: two resident workgroups per CU (2 x 72 KB LDS); 256-row tiles: one (108 KB)
     const int slots = (BMT == 128 ? 2 : 1) * pope_cu_count();

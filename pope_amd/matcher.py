@@ -165,5 +165,7 @@ class Matcher(nn.Module):
         self.fine_matching(win0, win1, data)
 
     def load_state_dict(self, state_dict, *args, **kwargs):
-        state_dict = {(k[len("matcher."):] if k.startswith("matcher.") else k): v for k, v in state_dict.items()}
+        # src/matcher/matcher.py:81-85: the keys are renamed IN THE CALLER'S dict (observable afterwards)
+        for old in [k for k in state_dict if k.startswith("matcher.")]:
+            state_dict[old[len("matcher."):]] = state_dict.pop(old)
         return super().load_state_dict(state_dict, *args, **kwargs)

@@ -4,7 +4,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import check, ptr, require_cuda, stream_of
+from ._lib import check, on_device_of, ptr, require_cuda, stream_of
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RES = 0, 1, 2
 
@@ -21,8 +21,9 @@ def layernorm(x, weight, bias, eps=1e-6):
     x = _f32c(x, "layernorm")
     dim = x.shape[-1]
     y = torch.empty_like(x)
-    check(_lib.lib().pope_layernorm_f32(ptr(x), ptr(_f32c(weight, "ln.w")), ptr(_f32c(bias, "ln.b")), ptr(y),
-                                        x.numel() // dim, dim, float(eps), stream_of(x.device)), "pope_layernorm_f32")
+    with on_device_of(x):
+        check(_lib.lib().pope_layernorm_f32(ptr(x), ptr(_f32c(weight, "ln.w")), ptr(_f32c(bias, "ln.b")), ptr(y),
+                                            x.numel() // dim, dim, float(eps), stream_of(x.device)), "pope_layernorm_f32")
     return y
 
 
@@ -36,8 +37,9 @@ def linear(a, weight, bias=None, epilogue=EPI_BIAS, gamma=None, res=None, out=No
     m = a.numel() // k
     if out is None:
         out = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32)
-    check(_lib.lib().pope_linear_prec_f32(ptr(a), ptr(weight), ptr(bias), ptr(out), m, n, k, epilogue, ptr(gamma),
-                                          ptr(res), _lib.PRECISIONS[precision], stream_of(a.device)), "pope_linear_prec_f32")
+    with on_device_of(a):
+        check(_lib.lib().pope_linear_prec_f32(ptr(a), ptr(weight), ptr(bias), ptr(out), m, n, k, epilogue, ptr(gamma),
+                                              ptr(res), _lib.PRECISIONS[precision], stream_of(a.device)), "pope_linear_prec_f32")
     return out
 
 
@@ -58,12 +60,14 @@ def patch_embed(img, proj_w, posb, patch, precision="f32"):
         kp = (pw.shape[1] + 31) // 32 * 32
         wp = _lib.to_planes(torch.nn.functional.pad(pw, (0, kp - pw.shape[1])), _lib.PLANES_W_SCALE)
         scratch = torch.empty(b * ntok * kp * 4, dtype=torch.uint8, device=img.device)
-        check(_lib.lib().pope_patch_embed_planes_f32(ptr(img), ptr(wp), ptr(_f32c(posb, "posb")), ptr(out), b, h, w, patch,
-                                                     dim, ptr(scratch), scratch.numel(), stream_of(img.device)),
-              "pope_patch_embed_planes_f32")
+        with on_device_of(img):
+            check(_lib.lib().pope_patch_embed_planes_f32(ptr(img), ptr(wp), ptr(_f32c(posb, "posb")), ptr(out), b, h, w, patch,
+                                                         dim, ptr(scratch), scratch.numel(), stream_of(img.device)),
+                  "pope_patch_embed_planes_f32")
         return out
-    check(_lib.lib().pope_patch_embed_f32(ptr(img), ptr(pw), ptr(_f32c(posb, "posb")),
-                                          ptr(out), b, h, w, patch, dim, stream_of(img.device)), "pope_patch_embed_f32")
+    with on_device_of(img):
+        check(_lib.lib().pope_patch_embed_f32(ptr(img), ptr(pw), ptr(_f32c(posb, "posb")),
+                                              ptr(out), b, h, w, patch, dim, stream_of(img.device)), "pope_patch_embed_f32")
     return out
 
 
@@ -73,8 +77,9 @@ def attention(qkv, heads, precision="f32"):
     b, n, d3 = qkv.shape
     assert d3 == 3 * heads * 64
     out = torch.empty(b, n, heads * 64, device=qkv.device, dtype=torch.float32)
-    check(_lib.lib().pope_attention_prec_f32(ptr(qkv), ptr(out), b, n, heads, _lib.PRECISIONS[precision],
-                                             stream_of(qkv.device)), "pope_attention_prec_f32")
+    with on_device_of(qkv):
+        check(_lib.lib().pope_attention_prec_f32(ptr(qkv), ptr(out), b, n, heads, _lib.PRECISIONS[precision],
+                                                 stream_of(qkv.device)), "pope_attention_prec_f32")
     return out
 
 
@@ -85,8 +90,9 @@ def cls_cosine(ref, fea, eps=1e-8):
     p, d = fea.shape
     assert ref.numel() == d
     scores = torch.empty(p, device=fea.device, dtype=torch.float32)
-    check(_lib.lib().pope_cls_cosine_f32(ptr(ref), ptr(fea), p, d, float(eps), ptr(scores), stream_of(fea.device)),
-          "pope_cls_cosine_f32")
+    with on_device_of(ref):
+        check(_lib.lib().pope_cls_cosine_f32(ptr(ref), ptr(fea), p, d, float(eps), ptr(scores), stream_of(fea.device)),
+              "pope_cls_cosine_f32")
     return scores
 
 

@@ -57,6 +57,10 @@ def test_state_dict_layout(msd):
         assert tuple(v.shape) == tuple(msd[k].shape), k
     with pytest.raises(RuntimeError):
         m.load_state_dict({k: v for k, v in msd.items() if k != "backbone.conv1.weight"}, strict=True)
+    # the `matcher.` prefix is stripped in the CALLER's dict, as the reference does (src/matcher/matcher.py:81-85)
+    prefixed = {"matcher." + k: v for k, v in msd.items()}
+    m.load_state_dict(prefixed, strict=True)
+    assert set(prefixed) == set(msd)
 
 
 @pytest.mark.parametrize("name", CASES)
