@@ -12,7 +12,13 @@ dense dual-softmax / mutual-NN matching of the 1530x1530 descriptor pairs (BASEL
 
 Pairs are independent: every rank works on its own batch (weak scaling, no data-path collective);
 the only exchange is the RCCL all_gather of per-pair match counts at the end of each step.
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  After the timed region the step's own outputs are spot-checked (pairs of the batch
+re-run one at a time must reproduce them bit for bit): `"verified": true`, non-zero exit otherwise.  At N = 1 the
+default run also times a short strict-fp32 leg (`strict_f32`) and the CPU oracle (`cpu_baseline`).
+
+`--workload linemod` (BASELINE config 4): one step = one pass over the 5 796 pair ids of the LINEMOD evaluation list
+(tests/golden/linemod_pairs.json; pixels synthetic, keyed by pair id), sharded contiguously over the ranks, walked
+in 128-pair batches with ragged tails, counts gathered once at the end (strong scaling).
 """
 import argparse
 import json
@@ -36,6 +42,7 @@ PEAK_HBM_GBS = 8000.0
 PRECISION_INFO = {"f16x3": ("f16x3 (fp32 operands split hi+lo into f16, 3 MFMAs per product, fp32 accumulate)",
                             PEAK_F16_MFMA_TFLOPS, 3),
                   "f32": ("f32 (v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS, 1)}
+PAIR_LIST = os.path.join(ROOT, "tests", "golden", "linemod_pairs.json")
 
 
 def flops_per_image(np_=NTOK - 1):
@@ -96,15 +103,44 @@ def cpu_baseline(n_pairs):
         return coarse_match_ref.dense_match(f0, f1, hw_c, hw_c, (H_IMG, W_IMG))
 
     run()  # warm-up
-    best = float("inf")
-    for _ in range(2):
+    times = []
+    for _ in range(3):
         t0 = time.perf_counter()
         out = run()
-        best = min(best, time.perf_counter() - t0)
-    return {"value": round(n_pairs / best, 4), "unit": "image-pairs/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{n_pairs} pairs 476x630 (batch {n_pairs} per forward), 1 warm-up + best of 2, "
-                      f"{int(len(out['i_ids']))} matches"}
+        times.append(time.perf_counter() - t0)
+    rates = sorted(n_pairs / t for t in times)
+    return {"value": round(rates[-1], 4), "unit": "image-pairs/s", "cores": torch.get_num_threads(),
+            "kind": "port", "runs_pairs_per_s": [round(r, 4) for r in rates],
+            "sample": f"{n_pairs} pairs 476x630 (batch {n_pairs} per forward), 1 warm-up + best of 3 "
+                      f"(all three listed: run-to-run spread on shared host cores), {int(len(out['i_ids']))} matches"}
+
+
+def verify_step(model, img0, img1, out, picks):
+    """The step's own outputs against the unbatched drop-in path: for each picked pair the two images are run
+    through the model alone and matched alone; descriptors, match indices and confidences must be bit-identical to
+    the pair's slice of the batched step (images and pairs are independent in the reference).  Returns a list of
+    failure strings (empty = verified)."""
+    from pope_amd.matcher import dense_match
+    hw_c = (H_IMG // PATCH, W_IMG // PATCH)
+    bad = []
+    counts = out["counts"]
+    if int(counts.sum()) != len(out["b_ids"]):
+        bad.append("counts do not add up to the match list")
+    for k in picks:
+        f0 = model(img0[k:k + 1], is_training=True)["x_norm_patchtokens"]
+        f1 = model(img1[k:k + 1], is_training=True)["x_norm_patchtokens"]
+        if not (torch.equal(f0[0], out["feat0"][k]) and torch.equal(f1[0], out["feat1"][k])):
+            bad.append(f"pair {k}: descriptors differ from the batch-1 run")
+        one = dense_match(f0, f1, hw_c, hw_c, (H_IMG, W_IMG), precision=getattr(model, "_bench_match_precision", None))
+        sel = out["b_ids"] == k
+        for key in ("i_ids", "j_ids", "mconf"):
+            if not torch.equal(out[key][sel], one[key]):
+                bad.append(f"pair {k}: {key} differs from the batch-1 run")
+        if int(counts[k]) != len(one["i_ids"]) or len(one["i_ids"]) < 500:
+            bad.append(f"pair {k}: {int(counts[k])} matches (batch-1 run: {len(one['i_ids'])}; planted: ~1131)")
+    if not bool(torch.isfinite(out["feat0"]).all()):
+        bad.append("non-finite descriptors")
+    return bad
 
 
 def main():
@@ -112,17 +148,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU per step (BASELINE config 3)")
+    ap.add_argument("--workload", choices=["batch128", "linemod"], default="batch128",
+                    help="batch128 = BASELINE config 3 (the headline metric); linemod = config 4 (whole pair list per step)")
+    ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU per step (BASELINE config 3) / per batch (linemod)")
     ap.add_argument("--chunk", type=int, default=64, help="images per ViT launch sequence (BASELINE config 2)")
     ap.add_argument("--cpu-pairs", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--no-strict-f32", action="store_true", help="skip the short strict-fp32 leg of the N = 1 run")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the ViT chunks of a step are spread over")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="dev: run the N-rank code path with every rank on cuda:0 and the gloo backend (collectives on "
                          "CPU copies) — checks the multi-process flow on a 1-GPU box; the numbers mean nothing")
     ap.add_argument("--precision", choices=sorted(PRECISION_INFO), default="f16x3",
-                    help="arithmetic of the Linear layers and attention (both are held to the same parity tests)")
+                    help="arithmetic of the Linear layers, attention and the matcher contraction (both are held to the "
+                         "same parity tests)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,32 +184,64 @@ def main():
 
     from pope_amd import synth
     from pope_amd.dinov2_utils import load_dinov2_model
-    from pope_amd.pipeline import PairPipeline, gather_counts
+    from pope_amd.pipeline import PairPipeline, gather_counts, load_pair_list, shard_range, walk_pair_list
 
     model = load_dinov2_model(state_dict=synth.synthetic_state_dict(seed=0)).to(device)
     model.precision = args.precision
+    model._bench_match_precision = args.precision
     dtype_name, peak_tflops, mfma_factor = PRECISION_INFO[args.precision]
-    pipe = PairPipeline(model, chunk=args.chunk, streams=args.streams)
+    pipe = PairPipeline(model, chunk=args.chunk, streams=args.streams, match_precision=args.precision)
     from pope_amd.profiling import KernelProfiler
-    n_chunks = -(-args.pairs // args.chunk) * 2  # ViT launch sequences per step
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    linemod = args.workload == "linemod"
+    if linemod:
+        # BASELINE config 4: the list is sharded contiguously; every rank pre-generates its shard's pixels in HBM
+        # (5 796 pairs x 2 x 3.6 MB = 41.7 GB at N = 1), keyed by pair id, before anything is timed
+        n_list = len(load_pair_list(PAIR_LIST))
+        lo, hi = shard_range(n_list, rank, world)
+        shard = {}
+        for s in range(lo, hi, args.pairs):
+            e = min(s + args.pairs, hi)
+            shard[s] = synth.pairs_by_id(torch.arange(s, e), H_IMG, W_IMG, device=device)
+        last = {}
+
+        def process_batch(s, e):
+            last["lo"], last["img"] = s, shard[s]
+            last["out"] = pipe(*shard[s])
+            return last["out"]["counts"]
+
+        def step():
+            counts, nb = walk_pair_list(n_list, process_batch, batch=args.pairs, rank=rank, world=world, device=coll_device)
+            return last["out"], counts, nb
+        pairs_per_step_total = n_list
+        n_chunks = sum(2 * -(-(min(s + args.pairs, hi) - s) // args.chunk) for s in range(lo, hi, args.pairs))
+    else:
+        img0, img1 = gpu_pairs(args.pairs, device, seed=rank)
+
+        def step():
+            out = pipe(img0, img1)
+            counts = gather_counts(out["counts"].to(coll_device))  # the only exchange: per-pair match counts
+            return out, counts, 1
+        pairs_per_step_total = args.pairs * world
+        n_chunks = -(-args.pairs // args.chunk) * 2  # ViT launch sequences per step
+
     # The LAST warm-up step runs with every launch bracketed by HIP events (the per-kernel table and the choice
     # of the dominant kernel); the timed steps bracket only that dominant kernel, so every other launch stays
     # back to back exactly as in the untimed product path (bracketing all ~86 launches per forward costs ~2 %).
     survey = None if (args.no_kernel_table or args.warmup < 1) else KernelProfiler(DEPTH, n_chunks)
     prof = None
-    img0, img1 = gpu_pairs(args.pairs, device, seed=rank)
-
-    def step():
-        out = pipe(img0, img1)
-        counts = gather_counts(out["counts"].to(coll_device))  # the only exchange: per-pair match counts
-        return out, counts
-
     dominant = "attention"
     for i in range(args.warmup):
         if survey is not None and i == args.warmup - 1:
             torch.cuda.synchronize()
             model.profiler = survey
-        out, counts = step()
+        out, counts, _ = step()
     model.profiler = None
     tab = []
     if survey is not None:
@@ -178,24 +250,18 @@ def main():
             fl, by = kernel_flops(kind, args.chunk), kernel_bytes(kind, args.chunk)
             tab.append({"kernel": kind, "launches": v["launches"], "avg_ms": round(v["avg_ms"], 4),
                         "ms_per_step": round(v["total_ms"], 3),
-                        "tflops": round(fl / v["avg_ms"] / 1e9, 2) if fl else None,
-                        "gbs": round(by / v["avg_ms"] / 1e6, 1) if by else None})
-        dominant = max((t for t in tab if t["tflops"]), key=lambda t: t["ms_per_step"])["kernel"]
+                        "tflops": round(fl / v["avg_ms"] / 1e9, 2) if (fl and not linemod) else None,
+                        "gbs": round(by / v["avg_ms"] / 1e6, 1) if (by and not linemod) else None})
+        dominant = max((t for t in tab if kernel_flops(t["kernel"], args.chunk)), key=lambda t: t["ms_per_step"])["kernel"]
         survey.close()
-    if not args.no_kernel_table:
+    if not args.no_kernel_table and not linemod:
         prof = KernelProfiler(DEPTH, n_chunks * args.steps, kinds=(dominant,))
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     fence()
     model.profiler = prof  # HIP events around every launch of the dominant kernel in the TIMED region
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out, counts = step()
+        out, counts, n_batches = step()
     fence()
     elapsed = time.perf_counter() - t0
     model.profiler = None
@@ -204,48 +270,65 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
-    total_pairs = args.pairs * world * args.steps
+    # ---- self-check of the timed step's own outputs (every rank; all must pass) --------------------------------
+    if linemod:
+        v_img0, v_img1 = last["img"]
+        picks = sorted({0, len(out["counts"]) // 2, len(out["counts"]) - 1})
+    else:
+        v_img0, v_img1 = img0, img1
+        picks = sorted({0, args.pairs // 2, args.pairs - 1})
+    failures = verify_step(model, v_img0, v_img1, out, picks)
+    if counts.numel() != pairs_per_step_total:
+        failures.append(f"gathered {counts.numel()} counts for {pairs_per_step_total} pairs")
+    if model.overflow_events:
+        failures.append(f"{model.overflow_events} f16x3 range-guard events on synthetic data")
+    ok = torch.tensor([0 if failures else 1], dtype=torch.int32, device=coll_device)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    verified = bool(int(ok))
+
+    total_pairs = pairs_per_step_total * args.steps
     value = total_pairs / elapsed
+    workload = ("extract(2 x DINOv2-S/14 @476x630 centre crop of 640x480, 1531 tokens) + dense "
+                "dual-softmax mutual-NN match (1530x1530x384) per pair")
     result = {
         "metric": "image-pairs/s (DINOv2-S/14 extract+match, 640x480)",
         "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
-        "config": {"workload": "extract(2 x DINOv2-S/14 @476x630 centre crop of 640x480, 1531 tokens) + dense "
-                               "dual-softmax mutual-NN match (1530x1530x384) per pair",
-                   "pairs_per_gpu_per_step": args.pairs, "vit_chunk_images": args.chunk,
+        "scaling": "strong" if linemod else "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+        "config": {"workload": workload + (f"; one step = the {pairs_per_step_total} pairs of the LINEMOD evaluation list "
+                                           f"(BASELINE config 4), {args.pairs}-pair batches with ragged tails"
+                                           if linemod else " (BASELINE config 3)"),
+                   "pairs_per_gpu_per_step": (hi - lo) if linemod else args.pairs, "vit_chunk_images": args.chunk,
                    "weights": "seeded synthetic, reference state-dict layout",
                    "parallelism": f"pairs sharded over {world} GPU(s); RCCL all_gather of match counts"},
         "gflop_per_pair": round(flops_per_pair() / 1e9, 3),
         "achieved_tflops_whole_step": round(value * flops_per_pair() / 1e12 / world, 2),
         "matches_per_pair_mean": round(float(counts.float().mean()), 1),
+        "verified": verified,
+        "verified_note": f"pairs {picks} of the last timed step re-run one at a time (batch-1 ViT + batch-1 matcher): "
+                         "descriptors, match indices and confidences bit-identical; counts consistent; no range-guard event",
     }
+    if linemod:
+        result["batches_per_rank_per_step"] = n_batches
+    if failures:
+        result["verify_failures"] = failures[:8]
     if prof is not None and rank == 0:
         v = prof.summary()[dominant]
         fl = kernel_flops(dominant, args.chunk)
         dom = {"kernel": dominant, "launches": v["launches"], "avg_ms": round(v["avg_ms"], 4),
                "tflops": round(fl / v["avg_ms"] / 1e9, 2)}
-        traffic = None  # PMC-derived bytes per launch, collected in separate rocprofv3 --pmc passes (profiles/)
-        try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(dominant)
-        except (OSError, ValueError):
-            pass
-        result["roofline"] = {
-            "kernel": dominant, "bound": "mfma", "achieved": dom["tflops"], "peak": peak_tflops,
-            "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak_tflops, 4), "traffic": traffic,
-            "mfma_flops_per_algorithmic_flop": mfma_factor,
-            "frac_of_executed_mfma_flops": round(mfma_factor * dom["tflops"] / peak_tflops, 4),
-            "algorithmic_bytes_per_launch": kernel_bytes(dominant, args.chunk),
-            "flops_per_launch": fl, "avg_ms_per_launch": dom["avg_ms"],
-            "launches_timed": dom["launches"],
-            "note": "algorithmic FLOPs / HIP-event duration of every launch of this kernel inside the timed "
-                    "region (events on the launch stream); peak = dense MFMA peak of the MFMA dtype "
-                    "(MI355X_MICROARCH.md); f16x3 executes 3 MFMA FLOPs per algorithmic FLOP",
-        }
+        result["roofline"] = roofline_entry(dominant, dom, peak_tflops, mfma_factor, args.chunk)
         if tab:
             result["kernels"] = tab
             result["kernels_note"] = "every launch of the last warm-up step bracketed by HIP events"
             result["vit_kernel_ms_per_step"] = round(sum(t["ms_per_step"] for t in tab), 3)
+    elif tab and rank == 0:
+        result["kernels"] = tab
+
+    # ---- N = 1 extras: strict-fp32 leg (driver-observed figure for the fp32-MFMA mode) and the CPU oracle -------
+    if rank == 0 and world == 1 and not linemod and args.precision != "f32" and not args.no_strict_f32:
+        result["strict_f32"] = strict_f32_leg(model, pipe, img0, img1, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N = 1 only (the other ranks would idle)
         result["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
     if world > 1:
@@ -253,6 +336,62 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+    if not verified:
+        raise SystemExit(3)
+
+
+def roofline_entry(dominant, dom, peak_tflops, mfma_factor, chunk):
+    traffic = None  # PMC-derived bytes per launch, collected in separate rocprofv3 --pmc passes (profiles/)
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(dominant)
+    except (OSError, ValueError):
+        pass
+    return {
+        "kernel": dominant, "bound": "mfma", "achieved": dom["tflops"], "peak": peak_tflops,
+        "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak_tflops, 4), "traffic": traffic,
+        "mfma_flops_per_algorithmic_flop": mfma_factor,
+        "frac_of_executed_mfma_flops": round(mfma_factor * dom["tflops"] / peak_tflops, 4),
+        "algorithmic_bytes_per_launch": kernel_bytes(dominant, chunk),
+        "flops_per_launch": kernel_flops(dominant, chunk), "avg_ms_per_launch": dom["avg_ms"],
+        "launches_timed": dom["launches"],
+        "note": "algorithmic FLOPs / HIP-event duration of every launch of this kernel inside the timed "
+                "region (events on the launch stream); peak = dense MFMA peak of the MFMA dtype "
+                "(MI355X_MICROARCH.md); f16x3 executes 3 MFMA FLOPs per algorithmic FLOP",
+    }
+
+
+def strict_f32_leg(model, pipe, img0, img1, args, steps=2):
+    """The same step with every contraction on the fp32-in MFMA (v_mfma_f32_32x32x2_f32: an exact k-ordered fp32 fma
+    chain — the reference's arithmetic): 1 warm-up + `steps` timed steps, attention bracketed."""
+    from pope_amd.profiling import KernelProfiler
+    dtype_name, peak, factor = PRECISION_INFO["f32"]
+    model.precision = pipe.match_precision = "f32"
+    try:
+        pipe(img0, img1)
+        n_chunks = -(-args.pairs // args.chunk) * 2
+        prof = KernelProfiler(DEPTH, n_chunks * steps, kinds=("attention",))
+        torch.cuda.synchronize()
+        model.profiler = prof
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = pipe(img0, img1)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        model.profiler = None
+        v = prof.summary()["attention"]
+        prof.close()
+        dom = {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"],
+               "tflops": round(kernel_flops("attention", args.chunk) / v["avg_ms"] / 1e9, 2)}
+        value = args.pairs * steps / elapsed
+        return {"value": round(value, 2), "unit": "image-pairs/s", "dtype": dtype_name, "steps": steps, "warmup": 1,
+                "ms_per_step": round(1e3 * elapsed / steps, 3),
+                "achieved_tflops_whole_step": round(value * flops_per_pair() / 1e12, 2),
+                "frac_of_f32_mfma_peak_whole_step": round(value * flops_per_pair() / 1e12 / peak, 4),
+                "matches_per_pair_mean": round(float(out["counts"].float().mean()), 1),
+                "roofline": roofline_entry("attention", dom, peak, factor, args.chunk)}
+    finally:
+        model.profiler = None
+        model.precision = pipe.match_precision = args.precision
 
 
 if __name__ == "__main__":

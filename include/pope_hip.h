@@ -8,9 +8,23 @@
  *
  * Conventions: every pointer is a DEVICE pointer unless the name ends in _host; tensors are
  * dense row-major fp32 in the reference's native layouts (torch Linear weight = [out, in]);
- * `stream` is a hipStream_t (NULL = default stream); no entry point allocates, synchronises
- * or keeps global state — workspaces are caller-provided (size query functions); return
- * value 0 = OK, negative = error (pope_error_string).  All work is enqueued asynchronously.
+ * `stream` is a hipStream_t; no entry point allocates or synchronises — workspaces are
+ * caller-provided (size query functions); return value 0 = OK, negative = error
+ * (pope_error_string).  All work is enqueued asynchronously.
+ * Devices: work is launched on the device that owns `stream`; for stream == NULL (the default
+ * stream, which does not name a device) on the calling thread's current device, so a caller with
+ * several GPUs makes the operands' device current first (pope_amd/_lib.py:on_device_of does).
+ * State: the library keeps, per device and filled lazily, the CU count and one "large dynamic
+ * LDS enabled" bit per kernel (atomics; idempotent) — nothing else, and nothing per call, so
+ * entry points may be called concurrently from several threads and for several devices.
+ *
+ * f16x3 range guard: POPE_PREC_F16X3 keeps operands as f16 pairs after a power-of-two scale
+ * (activations x8, weights and matcher features x256), i.e. it needs |activation| < 8190 and
+ * |weight| < 255.9.  Every entry point that converts values takes `range_flag`, an optional
+ * DEVICE word (NULL = no check) into which POPE_RANGE_* bits are ORed when a converted value
+ * would not be finite in f16 (or is not finite to begin with); the caller zeroes it, reads it at
+ * its next synchronisation point and re-runs the work with POPE_PREC_F32_MFMA, which has no range
+ * contract (pope_amd/dinov2.py, pope_amd/pipeline.py do exactly that).
  */
 #ifndef POPE_HIP_H
 #define POPE_HIP_H
@@ -21,7 +35,7 @@
 extern "C" {
 #endif
 
-#define POPE_ABI_VERSION 3
+#define POPE_ABI_VERSION 4
 
 enum {
     POPE_EPI_BIAS = 0,        /* C = A.W^T + bias                         nn.Linear                     */
@@ -36,6 +50,9 @@ enum {
  *                      v_mfma_f32_32x32x16_f16 per product block on the matrix cores: same or smaller error
  *                      than the fp32 chain for |x| < 65504 (measured against fp64), 2.4x+ faster. */
 enum { POPE_PREC_F32_MFMA = 0, POPE_PREC_F16X3 = 1 };
+/* bits of a range_flag word: which f16x3 producer saw a value out of range */
+enum { POPE_RANGE_PATCH = 1, POPE_RANGE_LAYERNORM = 2, POPE_RANGE_QKV = 4, POPE_RANGE_GELU = 8, POPE_RANGE_MATCH = 16,
+       POPE_RANGE_INPUT = 32 };
 
 int pope_abi_version(void);
 const char* pope_error_string(int code);
@@ -50,9 +67,11 @@ int pope_layernorm_f32(const float* x, const float* weight, const float* bias, f
  * gamma[N] and res[M,N] only for POPE_EPI_BIAS_LS_RES (res may alias C). */
 int pope_linear_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
                     int epilogue, const float* gamma, const float* res, void* stream);
-/* Same with an explicit POPE_PREC_* (pope_linear_f32 == POPE_PREC_F32_MFMA). */
+/* Same with an explicit POPE_PREC_* (pope_linear_f32 == POPE_PREC_F32_MFMA).  POPE_PREC_F16X3 splits A and W inside
+ * the kernel; with range_flag both operands are scanned first (POPE_RANGE_INPUT). */
 int pope_linear_prec_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
-                         int epilogue, const float* gamma, const float* res, int precision, void* stream);
+                         int epilogue, const float* gamma, const float* res, int precision,
+                         unsigned* range_flag, void* stream);
 
 /* f16x3 "planes": a tensor X[rows, cols] (cols % 32 == 0) kept as f16 halves with X * scale = hi + lo
  * (scale a power of two: POPE_PLANES_ACT_SCALE for activations, POPE_PLANES_W_SCALE for weights), laid
@@ -63,16 +82,17 @@ int pope_linear_prec_f32(const float* A, const float* W, const float* bias, floa
  * stages MFMA-ready operands with no conversion work in its K loop. */
 #define POPE_PLANES_ACT_SCALE 8.0f
 #define POPE_PLANES_W_SCALE 256.0f
-int pope_split_planes_f32(const float* src, void* planes, int rows, int cols, float scale, void* stream);
+int pope_split_planes_f32(const float* src, void* planes, int rows, int cols, float scale,
+                          unsigned* range_flag, void* stream);
 /* nn.Linear on planes: A planes [M,K], W planes [N,K]; output either fp32 C[M,N] (c_planes == NULL) or
  * activation planes [M,N] (C == NULL; not for POPE_EPI_BIAS_LS_RES).  K % 32 == 0, K >= 64. */
 int pope_linear_planes_f32(const void* a_planes, const void* w_planes, const float* bias, float* C,
                            void* c_planes, int M, int N, int K, int epilogue, const float* gamma,
-                           const float* res, void* stream);
+                           const float* res, unsigned* range_flag, void* stream);
 
 /* LayerNorm written as activation planes [rows, dim]. */
 int pope_layernorm_planes_f32(const float* x, const float* weight, const float* bias, void* y_planes,
-                              int rows, int dim, float eps, void* stream);
+                              int rows, int dim, float eps, unsigned* range_flag, void* stream);
 
 /* PatchEmbed.forward + prepare_tokens_with_masks — patch_embed.py:69-82,
  * vision_transformer.py:191-200.  img[B,3,H,W]; proj_w[dim, 3*patch*patch];
@@ -85,14 +105,17 @@ int pope_patch_embed_f32(const float* img, const float* proj_w, const float* pos
  * [dim, kp] (weight planes, zero-padded columns); posb as above. */
 int pope_patch_embed_planes_f32(const float* img, const void* proj_w_planes, const float* posb, float* tokens,
                                 int B, int H, int W, int patch, int dim, void* a_planes_scratch,
-                                size_t scratch_bytes, void* stream);
+                                size_t scratch_bytes, unsigned* range_flag, void* stream);
 
 /* Attention.forward core — attention.py:51-59: qkv[B,N,3,heads,64] -> out[B,N,heads*64],
  * softmax((q*0.125) k^T) v. */
 int pope_attention_f32(const float* qkv, float* out, int B, int N, int heads, void* stream);
-/* Same with an explicit POPE_PREC_* (pope_attention_f32 == POPE_PREC_F32_MFMA). */
-int pope_attention_prec_f32(const float* qkv, float* out, int B, int N, int heads, int precision, void* stream);
-/* f16x3 attention on planes (layout and scale: POPE_PLANES_* below): qkv_planes [B*N, 3*heads*64] as written by
+/* Same with an explicit POPE_PREC_* (pope_attention_f32 == POPE_PREC_F32_MFMA); with range_flag a POPE_PREC_F16X3
+ * call scans qkv first (POPE_RANGE_INPUT). */
+int pope_attention_prec_f32(const float* qkv, float* out, int B, int N, int heads, int precision,
+                            unsigned* range_flag, void* stream);
+/* f16x3 attention on planes (layout and scale: POPE_PLANES_* above; the producer of the planes guards the range:
+ * the output is a convex combination of v rows, so it fits whenever v did): qkv_planes [B*N, 3*heads*64] as written by
  * pope_linear_planes_f32(..., c_planes), out_planes [B*N, heads*64] as read by the proj GEMM.  heads*64 % 32 == 0. */
 int pope_attention_planes_f32(const void* qkv_planes, void* out_planes, int B, int N, int heads, void* stream);
 
@@ -136,7 +159,7 @@ size_t pope_vit_workspace_bytes(int B, int ntok, int dim, int hidden);
 int pope_vit_forward_f32(const pope_vit_weights* w_host, const float* img, int B, int H, int W,
                          const float* posb, float* x_prenorm, float* x_norm,
                          int n_taps, const int* tap_blocks_host, float* const* tap_out_host,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         void* workspace, size_t workspace_bytes, unsigned* range_flag, void* stream);
 
 /* In-situ kernel timing of the product path (bench.py's roofline leg): identical launches, plus
  * events_host[i] (hipEvent_t made by pope_event_create) recorded on `stream` immediately before
@@ -145,19 +168,13 @@ int pope_vit_forward_f32(const pope_vit_weights* w_host, const float* img, int B
 enum { POPE_K_PATCH_EMBED = 0, POPE_K_LAYERNORM = 1, POPE_K_GEMM_QKV = 2, POPE_K_ATTENTION = 3,
        POPE_K_GEMM_PROJ = 4, POPE_K_GEMM_FC1 = 5, POPE_K_GEMM_FC2 = 6, POPE_K_TAP_COPY = 7 };
 int pope_vit_launch_count(int depth);
-int pope_vit_forward_profiled_f32(const pope_vit_weights* w_host, const float* img, int B, int H, int W,
-                                  const float* posb, float* x_prenorm, float* x_norm,
-                                  void* workspace, size_t workspace_bytes, void* stream,
-                                  void* const* events_host, int n_events, int* kinds_host,
-                                  int* n_launches_host);
-/* Same, but only launches whose POPE_K_* bit is set in kind_mask are bracketed (an event before and one after
- * each): timing one kernel kind leaves every other launch of the sequence back to back, as in the untimed
- * path.  events_host[i] / kinds_host[i] then hold the recorded events in order; kinds_host[i] is the kind
+/* Only launches whose POPE_K_* bit is set in kind_mask are bracketed (an event before and one after each; ~0u =
+ * all): timing one kernel kind leaves every other launch of the sequence back to back, as in the untimed path.  events_host[i] / kinds_host[i] then hold the recorded events in order; kinds_host[i] is the kind
  * of the launch that STARTS at event i, or -1 for an event that only closes the previous bracket;
  * *n_launches_host = number of recorded events - 1. */
 int pope_vit_forward_profiled_mask_f32(const pope_vit_weights* w_host, const float* img, int B, int H, int W,
                                        const float* posb, float* x_prenorm, float* x_norm,
-                                       void* workspace, size_t workspace_bytes, void* stream,
+                                       void* workspace, size_t workspace_bytes, unsigned* range_flag, void* stream,
                                        void* const* events_host, int n_events, int* kinds_host,
                                        int* n_launches_host, unsigned kind_mask);
 int pope_event_create(void** event_host);
@@ -191,7 +208,8 @@ int pope_dense_match_prec_f32(const float* feat0, long long stride0, const float
                               float thr, int border_rm, float temperature, float scale,
                               float* conf_matrix, long long* b_ids, long long* i_ids, long long* j_ids,
                               float* mconf, float* mkpts0_c, float* mkpts1_c, int* counts,
-                              void* workspace, size_t workspace_bytes, int precision, void* stream);
+                              void* workspace, size_t workspace_bytes, int precision, unsigned* range_flag,
+                              void* stream);
 
 /* ---- host-side helper ------------------------------------------------------------------------ */
 

@@ -208,6 +208,33 @@ def gen_driver():
     np.savez(os.path.join(OUT, "driver_pair.npz"), **fx)
 
 
+def gen_pair_lists():
+    """The work list of BASELINE config 4: the pair ids of the reference's data/pairs/LINEMOD-test.json (13 objects x
+    6 rotation bins, 5 796 pairs: eval_linemod_json.py:36-58 walks objects, then bins, then pairs).  Only the ids
+    travel — "<dir>/<idx0>.png-<idx1>.png" entries become [idx0, idx1] integer pairs under their object directory;
+    the images themselves are not in the reference tree (data/LM_dataset is a download) and pixels stay synthetic."""
+    import json
+    with open(os.path.join(REF, "data", "pairs", "LINEMOD-test.json")) as f:
+        doc = json.load(f)
+    objects = []
+    for obj in doc:
+        dirs = {os.path.dirname(p) for pairs in obj.values() for p in pairs}
+        assert len(dirs) == 1
+        bins = {}
+        for key, pairs in obj.items():
+            ids = []
+            for p in pairs:
+                a, b = os.path.basename(p).split("-")
+                ids.append([int(a.split(".")[0]), int(b.split(".")[0])])
+            bins[key] = ids
+        objects.append({"dir": dirs.pop(), "bins": bins})
+    n = sum(len(v) for o in objects for v in o["bins"].values())
+    assert len(objects) == 13 and n == 5796
+    with open(os.path.join(OUT, "linemod_pairs.json"), "w") as f:
+        json.dump({"source": "data/pairs/LINEMOD-test.json", "n_pairs": n, "objects": objects}, f, separators=(",", ":"))
+    print("linemod_pairs.json:", n, "pairs")
+
+
 def sd_digest(sd):
     return np.array([float(sd[k].double().sum()) for k in sorted(sd)], np.float64)
 
@@ -235,6 +262,8 @@ def run_ref_vit(model, x):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-pairs" in sys.argv:
+        return gen_pair_lists()
     if "--only-loftr" in sys.argv:
         return gen_loftr()
     if "--only-driver" in sys.argv:
@@ -348,6 +377,7 @@ def main():
              slot_scores=slots, slot_index=np.array(top))
     gen_loftr()
     gen_driver()
+    gen_pair_lists()
     print("golden fixtures written to", OUT)
 
 

@@ -33,34 +33,36 @@ class VitWeights(C.Structure):
 PREC_F32_MFMA, PREC_F16X3 = 0, 1
 PLANES_ACT_SCALE, PLANES_W_SCALE = 8.0, 256.0
 PRECISIONS = {"f32": PREC_F32_MFMA, "f16x3": PREC_F16X3}
+c_uint_p = C.POINTER(C.c_uint)
+F16_MAX = 65504.0
+# bits of an f16x3 range-guard word (pope_hip.h POPE_RANGE_*)
+RANGE_BITS = {1: "patch embed input", 2: "LayerNorm output", 4: "q/k/v", 8: "MLP hidden (GELU output)",
+              16: "matcher features", 32: "op-level operand"}
 
 PROTOTYPES = {
     "pope_abi_version": (C.c_int, []),
     "pope_error_string": (C.c_char_p, [C.c_int]),
     "pope_layernorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pope_linear_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 3),
-    "pope_linear_prec_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 2 + [C.c_int, C.c_void_p]),
-    "pope_split_planes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
-    "pope_linear_planes_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p] * 3),
-    "pope_layernorm_planes_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "pope_linear_prec_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 2 + [C.c_int, C.c_void_p, C.c_void_p]),
+    "pope_split_planes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "pope_linear_planes_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p] * 4),
+    "pope_layernorm_planes_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "pope_patch_embed_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "pope_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "pope_attention_prec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "pope_patch_embed_planes_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pope_attention_prec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pope_patch_embed_planes_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pope_attention_planes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pope_cls_cosine_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "pope_vit_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "pope_vit_forward_f32": (C.c_int, [C.POINTER(VitWeights), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int, c_int_p, C.POINTER(C.c_void_p),
-                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pope_vit_launch_count": (C.c_int, [C.c_int]),
-    "pope_vit_forward_profiled_f32": (C.c_int, [C.POINTER(VitWeights), C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
-                                                C.POINTER(C.c_void_p), C.c_int, c_int_p, c_int_p]),
     "pope_vit_forward_profiled_mask_f32": (C.c_int, [C.POINTER(VitWeights), C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
-                                                     C.c_void_p, C.POINTER(C.c_void_p), C.c_int, c_int_p, c_int_p,
-                                                     C.c_uint]),
+                                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, c_int_p,
+                                                     c_int_p, C.c_uint]),
     "pope_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "pope_event_destroy": (C.c_int, [C.c_void_p]),
     "pope_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, c_float_p]),
@@ -71,7 +73,7 @@ PROTOTYPES = {
     "pope_dense_match_workspace_bytes_prec": (C.c_size_t, [C.c_int] * 5),
     "pope_dense_match_prec_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 8
                                   + [C.c_float, C.c_int, C.c_float, C.c_float] + [C.c_void_p] * 8
-                                  + [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+                                  + [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "pope_streaming_top3_host": (C.c_int, [c_float_p, C.c_int, c_float_p, c_ll_p]),
 }
 
@@ -110,7 +112,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.pope_abi_version() != 3:
+        if handle.pope_abi_version() != 4:
             raise RuntimeError("libpope_hip.so ABI version mismatch")
         _lib = handle
     return _lib
@@ -118,6 +120,15 @@ def lib():
 
 class PopeHipError(RuntimeError):
     pass
+
+
+class PopeRangeError(PopeHipError):
+    """An f16x3 operand left the f16 range (|activation| * 8 or |weight| * 256 >= 65504): results of that call are not
+    valid; raised when the model's `on_overflow` policy is "raise" (the default policy re-runs on the fp32 MFMA)."""
+
+
+def describe_range_bits(bits):
+    return ", ".join(name for bit, name in RANGE_BITS.items() if bits & bit) or "none"
 
 
 def check(status, what):

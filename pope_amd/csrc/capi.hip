@@ -97,11 +97,12 @@ int pope_layernorm_f32(const float* x, const float* weight, const float* bias, f
 
 int pope_linear_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
                     int epilogue, const float* gamma, const float* res, void* stream) {
-    return pope_linear_prec_f32(A, W, bias, C, M, N, K, epilogue, gamma, res, POPE_PREC_F32_MFMA, stream);
+    return pope_linear_prec_f32(A, W, bias, C, M, N, K, epilogue, gamma, res, POPE_PREC_F32_MFMA, nullptr, stream);
 }
 
 int pope_linear_prec_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
-                         int epilogue, const float* gamma, const float* res, int precision, void* stream) {
+                         int epilogue, const float* gamma, const float* res, int precision, unsigned* range_flag,
+                         void* stream) {
     StreamDevice on_device(stream);
     if (!A || !W || !C || epilogue < 0 || epilogue > POPE_EPI_BIAS_LS_RES) return POPE_ERR_ARG;
     if (precision != POPE_PREC_F32_MFMA && precision != POPE_PREC_F16X3) return POPE_ERR_ARG;
@@ -111,22 +112,26 @@ int pope_linear_prec_f32(const float* A, const float* W, const float* bias, floa
     g.M = M; g.N = N; g.K = K;
     g.epilogue = epilogue;
     g.gamma = gamma; g.res = res; g.ldres = N;
+    g.range_flag = range_flag;
     // shapes the f16x3 kernel does not take (K % 32 != 0) run on the fp32 MFMA: same contract, same results
     if (precision == POPE_PREC_F16X3 && pope_gemm_f16x3_supported(g))
         return pope_launch_gemm_nt_f16x3(g, static_cast<hipStream_t>(stream));
     return pope_launch_gemm_nt_f32(g, static_cast<hipStream_t>(stream));
 }
 
-int pope_split_planes_f32(const float* src, void* planes, int rows, int cols, float scale, void* stream) {
+int pope_split_planes_f32(const float* src, void* planes, int rows, int cols, float scale, unsigned* range_flag, void* stream) {
     StreamDevice on_device(stream);
-    return pope_launch_split_planes(src, planes, rows, cols, scale, static_cast<hipStream_t>(stream));
+    return pope_launch_split_planes(src, planes, rows, cols, scale, range_flag, static_cast<hipStream_t>(stream));
 }
 
 int pope_linear_planes_f32(const void* a_planes, const void* w_planes, const float* bias, float* C, void* c_planes,
-                           int M, int N, int K, int epilogue, const float* gamma, const float* res, void* stream) {
+                           int M, int N, int K, int epilogue, const float* gamma, const float* res, unsigned* range_flag,
+                           void* stream) {
     StreamDevice on_device(stream);
     if (epilogue < 0 || epilogue > POPE_EPI_BIAS_LS_RES) return POPE_ERR_ARG;
     GemmParams g = {};
+    g.range_flag = range_flag;
+    g.range_bit = epilogue == POPE_EPI_BIAS_GELU ? POPE_RANGE_GELU : POPE_RANGE_QKV;
     g.a_pl = a_planes; g.w_pl = w_planes;
     g.bias = bias; g.C = C; g.c_pl = c_planes;
     g.lda = K; g.ldw = K; g.ldc = N;
@@ -137,10 +142,10 @@ int pope_linear_planes_f32(const void* a_planes, const void* w_planes, const flo
 }
 
 int pope_layernorm_planes_f32(const float* x, const float* weight, const float* bias, void* y_planes, int rows, int dim,
-                              float eps, void* stream) {
+                              float eps, unsigned* range_flag, void* stream) {
     StreamDevice on_device(stream);
     if (!x || !weight || !bias) return POPE_ERR_ARG;
-    return pope_launch_layernorm_planes(x, dim, weight, bias, y_planes, rows, dim, eps, static_cast<hipStream_t>(stream));
+    return pope_launch_layernorm_planes(x, dim, weight, bias, y_planes, rows, dim, eps, range_flag, static_cast<hipStream_t>(stream));
 }
 
 int pope_patch_embed_f32(const float* img, const float* proj_w, const float* posb, float* tokens, int B, int H,
@@ -160,14 +165,15 @@ int pope_patch_embed_f32(const float* img, const float* proj_w, const float* pos
 }
 
 int pope_patch_embed_planes_f32(const float* img, const void* proj_w_planes, const float* posb, float* tokens, int B, int H,
-                                int W, int patch, int dim, void* a_planes_scratch, size_t scratch_bytes, void* stream_) {
+                                int W, int patch, int dim, void* a_planes_scratch, size_t scratch_bytes, unsigned* range_flag,
+                                void* stream_) {
     StreamDevice on_device(stream_);
     if (!img || !proj_w_planes || !posb || !tokens || !a_planes_scratch || B <= 0 || patch <= 0 || H % patch || W % patch)
         return POPE_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int kp = (3 * patch * patch + 31) & ~31, ntok = 1 + (H / patch) * (W / patch);
     if (scratch_bytes < size_t(B) * ntok * kp * 4) return POPE_ERR_WORKSPACE;
-    int rc = pope_launch_im2col_planes(img, a_planes_scratch, B, H, W, patch, kp, stream);
+    int rc = pope_launch_im2col_planes(img, a_planes_scratch, B, H, W, patch, kp, range_flag, stream);
     if (rc) return rc;
     // tokens[b, n] = posb[n] + 1 * (A[b, n] . W^T): rows n = 0 are all-zero A rows (cls_token + pos_embed[0] from the table)
     GemmParams g = {};
@@ -187,12 +193,19 @@ int pope_attention_planes_f32(const void* qkv_planes, void* out_planes, int B, i
 }
 
 int pope_attention_f32(const float* qkv, float* out, int B, int N, int heads, void* stream) {
-    return pope_attention_prec_f32(qkv, out, B, N, heads, POPE_PREC_F32_MFMA, stream);
+    return pope_attention_prec_f32(qkv, out, B, N, heads, POPE_PREC_F32_MFMA, nullptr, stream);
 }
 
-int pope_attention_prec_f32(const float* qkv, float* out, int B, int N, int heads, int precision, void* stream) {
+int pope_attention_prec_f32(const float* qkv, float* out, int B, int N, int heads, int precision, unsigned* range_flag,
+                            void* stream) {
     StreamDevice on_device(stream);
     if (!qkv || !out) return POPE_ERR_ARG;
+    if (precision == POPE_PREC_F16X3 && range_flag) {  // q, k, v are split inside the kernel: check them in a scan
+        if (B <= 0 || N <= 0 || heads <= 0) return POPE_ERR_ARG;
+        const int rc = pope_launch_range_check(qkv, size_t(B) * N * 3 * heads * 64, 1.0f, range_flag, POPE_RANGE_INPUT,
+                                               static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+    }
     if (precision == POPE_PREC_F16X3) return pope_launch_attention_f16x3(qkv, out, B, N, heads, static_cast<hipStream_t>(stream));
     if (precision != POPE_PREC_F32_MFMA) return POPE_ERR_ARG;
     return pope_launch_attention_f32(qkv, out, B, N, heads, static_cast<hipStream_t>(stream));
@@ -215,8 +228,8 @@ size_t pope_vit_workspace_bytes(int B, int ntok, int dim, int hidden) {
 
 static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, int H, int W, const float* posb,
                             float* x_prenorm, float* x_norm, int n_taps, const int* tap_blocks_host,
-                            float* const* tap_out_host, void* workspace, size_t workspace_bytes, void* stream_,
-                            Recorder& rec) {
+                            float* const* tap_out_host, void* workspace, size_t workspace_bytes, unsigned* range_flag,
+                            void* stream_, Recorder& rec) {
     StreamDevice on_device(stream_);
     if (!w || !img || !posb || !x_prenorm || !workspace || !w->blocks_host) return POPE_ERR_ARG;
     if (w->dim != w->heads * 64 || w->patch <= 0 || H % w->patch || W % w->patch || B <= 0) return POPE_ERR_ARG;
@@ -238,71 +251,59 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
     float* x = x_prenorm;
     const float eps = 1e-6f;  // vision_transformer.py:90
 
+    // f16x3 = the planes dataflow end to end (every operand is split ONCE by its producer, which also guards the f16
+    // range: range_flag).  It needs the weight planes of all four Linear layers of every block; without them (or with
+    // a width the planes layout does not take) the model runs on the fp32 MFMA, which has no range contract.
+    bool planes = prec == POPE_PREC_F16X3 && dim % 32 == 0 && dim >= 64 && hidden % 32 == 0;
+    for (int i = 0; planes && i < w->depth; ++i) {
+        const pope_vit_block_weights& k = w->blocks_host[i];
+        planes = k.qkv_wp && k.proj_wp && k.fc1_wp && k.fc2_wp;
+    }
+    const int f32 = POPE_PREC_F32_MFMA;
+
 #define POPE_MARK(kind) do { if (!rec.mark(kind, stream)) return POPE_ERR_ARG; } while (0)
+#define POPE_TRY(call) do { if ((rc = (call))) return rc; } while (0)
     POPE_MARK(POPE_K_PATCH_EMBED);
     int rc;
-    if (prec == POPE_PREC_F16X3 && w->patch_wp && dim % 4 == 0)  // `big` is free here: it holds the im2col planes
-        rc = pope_patch_embed_planes_f32(img, w->patch_wp, posb, x, B, H, W, w->patch, dim, big,
-                                         workspace_bytes - size_t(reinterpret_cast<char*>(big) - ws), stream);
+    if (planes && w->patch_wp)  // `big` is free here: it holds the im2col planes
+        POPE_TRY(pope_patch_embed_planes_f32(img, w->patch_wp, posb, x, B, H, W, w->patch, dim, big,
+                                             workspace_bytes - size_t(reinterpret_cast<char*>(big) - ws), range_flag, stream));
     else
-        rc = pope_patch_embed_f32(img, w->patch_w, posb, x, B, H, W, w->patch, dim, stream);
-    if (rc) return rc;
+        POPE_TRY(pope_patch_embed_f32(img, w->patch_w, posb, x, B, H, W, w->patch, dim, stream));
     for (int i = 0; i < w->depth; ++i) {
         const pope_vit_block_weights& k = w->blocks_host[i];
-        // x = x + ls1(attn(norm1(x)))                                      block.py:105
-        const bool planes = prec == POPE_PREC_F16X3 && k.qkv_wp && k.fc1_wp && k.fc2_wp && dim % 32 == 0 && dim >= 64;
-        const bool proj_planes = planes && k.proj_wp;
         void* xn_pl = xn;    // planes alias the xn / fc1 buffers: 2 x f16 per element = the fp32 footprint
         void* hid_pl = hid;
+        // x = x + ls1(attn(norm1(x)))                                      block.py:105
         POPE_MARK(POPE_K_LAYERNORM);
-        if (planes) {
-            if ((rc = pope_launch_layernorm_planes(x, dim, k.norm1_w, k.norm1_b, xn_pl, rows, dim, eps, stream))) return rc;
-        } else {
-            if ((rc = pope_launch_layernorm_f32(x, dim, k.norm1_w, k.norm1_b, xn, dim, rows, dim, eps, stream))) return rc;
-        }
+        if (planes) POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm1_w, k.norm1_b, xn_pl, rows, dim, eps, range_flag, stream));
+        else POPE_TRY(pope_launch_layernorm_f32(x, dim, k.norm1_w, k.norm1_b, xn, dim, rows, dim, eps, stream));
         POPE_MARK(POPE_K_GEMM_QKV);
-        if (proj_planes) {  // q, k, v stay planes from the QKV epilogue to the attention kernel's LDS
-            if ((rc = pope_linear_planes_f32(xn_pl, k.qkv_wp, k.qkv_b, nullptr, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr,
-                                             stream))) return rc;
-        } else if (planes) {
-            if ((rc = pope_linear_planes_f32(xn_pl, k.qkv_wp, k.qkv_b, qkv, nullptr, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr,
-                                             stream))) return rc;
-        } else {
-            if ((rc = pope_linear_prec_f32(xn, k.qkv_w, k.qkv_b, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, prec, stream))) return rc;
-        }
+        if (planes)  // q, k, v stay planes from the QKV epilogue to the attention kernel's LDS
+            POPE_TRY(pope_linear_planes_f32(xn_pl, k.qkv_wp, k.qkv_b, nullptr, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr,
+                                            range_flag, stream));
+        else POPE_TRY(pope_linear_prec_f32(xn, k.qkv_w, k.qkv_b, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, f32, nullptr, stream));
         POPE_MARK(POPE_K_ATTENTION);
-        if (proj_planes) {
-            if ((rc = pope_launch_attention_f16x3_planes_io(qkv, att, B, ntok, w->heads, stream))) return rc;
-        } else {
-            if ((rc = pope_attention_prec_f32(qkv, att, B, ntok, w->heads, prec, stream))) return rc;
-        }
+        if (planes) POPE_TRY(pope_launch_attention_f16x3_planes_io(qkv, att, B, ntok, w->heads, stream));
+        else POPE_TRY(pope_attention_prec_f32(qkv, att, B, ntok, w->heads, f32, nullptr, stream));
         POPE_MARK(POPE_K_GEMM_PROJ);
-        if (proj_planes) {
-            if ((rc = pope_linear_planes_f32(att, k.proj_wp, k.proj_b, x, nullptr, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, stream))) return rc;
-        } else {
-            if ((rc = pope_linear_prec_f32(att, k.proj_w, k.proj_b, x, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, prec, stream))) return rc;
-        }
+        if (planes)
+            POPE_TRY(pope_linear_planes_f32(att, k.proj_wp, k.proj_b, x, nullptr, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, nullptr, stream));
+        else POPE_TRY(pope_linear_prec_f32(att, k.proj_w, k.proj_b, x, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, f32, nullptr, stream));
         // x = x + ls2(mlp(norm2(x)))                                       block.py:106
         POPE_MARK(POPE_K_LAYERNORM);
-        if (planes) {
-            if ((rc = pope_launch_layernorm_planes(x, dim, k.norm2_w, k.norm2_b, xn_pl, rows, dim, eps, stream))) return rc;
-        } else {
-            if ((rc = pope_launch_layernorm_f32(x, dim, k.norm2_w, k.norm2_b, xn, dim, rows, dim, eps, stream))) return rc;
-        }
+        if (planes) POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm2_w, k.norm2_b, xn_pl, rows, dim, eps, range_flag, stream));
+        else POPE_TRY(pope_launch_layernorm_f32(x, dim, k.norm2_w, k.norm2_b, xn, dim, rows, dim, eps, stream));
         POPE_MARK(POPE_K_GEMM_FC1);
-        if (planes) {
-            if ((rc = pope_linear_planes_f32(xn_pl, k.fc1_wp, k.fc1_b, nullptr, hid_pl, rows, hidden, dim, EPI_BIAS_GELU, nullptr,
-                                             nullptr, stream))) return rc;
-        } else {
-            if ((rc = pope_linear_prec_f32(xn, k.fc1_w, k.fc1_b, hid, rows, hidden, dim, EPI_BIAS_GELU, nullptr, nullptr, prec, stream))) return rc;
-        }
+        if (planes)
+            POPE_TRY(pope_linear_planes_f32(xn_pl, k.fc1_wp, k.fc1_b, nullptr, hid_pl, rows, hidden, dim, EPI_BIAS_GELU, nullptr,
+                                            nullptr, range_flag, stream));
+        else POPE_TRY(pope_linear_prec_f32(xn, k.fc1_w, k.fc1_b, hid, rows, hidden, dim, EPI_BIAS_GELU, nullptr, nullptr, f32, nullptr, stream));
         POPE_MARK(POPE_K_GEMM_FC2);
-        if (planes) {
-            if ((rc = pope_linear_planes_f32(hid_pl, k.fc2_wp, k.fc2_b, x, nullptr, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x,
-                                             stream))) return rc;
-        } else {
-            if ((rc = pope_linear_prec_f32(hid, k.fc2_w, k.fc2_b, x, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x, prec, stream))) return rc;
-        }
+        if (planes)
+            POPE_TRY(pope_linear_planes_f32(hid_pl, k.fc2_wp, k.fc2_b, x, nullptr, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x,
+                                            nullptr, stream));
+        else POPE_TRY(pope_linear_prec_f32(hid, k.fc2_w, k.fc2_b, x, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x, f32, nullptr, stream));
         for (int t = 0; t < n_taps; ++t)
             if (tap_blocks_host[t] == i && tap_out_host[t]) {
                 POPE_MARK(POPE_K_TAP_COPY);
@@ -313,9 +314,10 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
     }
     if (x_norm) {
         POPE_MARK(POPE_K_LAYERNORM);
-        if ((rc = pope_launch_layernorm_f32(x, dim, w->norm_w, w->norm_b, x_norm, dim, rows, dim, eps, stream))) return rc;
+        POPE_TRY(pope_launch_layernorm_f32(x, dim, w->norm_w, w->norm_b, x_norm, dim, rows, dim, eps, stream));
     }
     POPE_MARK(-1);  // closing event
+#undef POPE_TRY
 #undef POPE_MARK
     return POPE_OK;
 }
@@ -323,31 +325,25 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
 
 int pope_vit_forward_f32(const pope_vit_weights* w, const float* img, int B, int H, int W, const float* posb,
                          float* x_prenorm, float* x_norm, int n_taps, const int* tap_blocks_host,
-                         float* const* tap_out_host, void* workspace, size_t workspace_bytes, void* stream) {
+                         float* const* tap_out_host, void* workspace, size_t workspace_bytes, unsigned* range_flag,
+                         void* stream) {
     Recorder rec{nullptr, 0, nullptr, 0};
     return vit_forward_impl(w, img, B, H, W, posb, x_prenorm, x_norm, n_taps, tap_blocks_host, tap_out_host, workspace,
-                            workspace_bytes, stream, rec);
+                            workspace_bytes, range_flag, stream, rec);
 }
 
 int pope_vit_forward_profiled_mask_f32(const pope_vit_weights* w, const float* img, int B, int H, int W,
                                        const float* posb, float* x_prenorm, float* x_norm, void* workspace,
-                                       size_t workspace_bytes, void* stream, void* const* events_host, int n_events,
-                                       int* kinds_host, int* n_launches_host, unsigned kind_mask) {
+                                       size_t workspace_bytes, unsigned* range_flag, void* stream,
+                                       void* const* events_host, int n_events, int* kinds_host, int* n_launches_host,
+                                       unsigned kind_mask) {
     if (!events_host || n_events < 2 || !kinds_host || !n_launches_host) return POPE_ERR_ARG;
     Recorder rec{events_host, n_events, kinds_host, 0};
     rec.mask = kind_mask;
     const int rc = vit_forward_impl(w, img, B, H, W, posb, x_prenorm, x_norm, 0, nullptr, nullptr, workspace,
-                                    workspace_bytes, stream, rec);
+                                    workspace_bytes, range_flag, stream, rec);
     *n_launches_host = rec.n > 0 ? rec.n - 1 : 0;
     return rc;
-}
-
-int pope_vit_forward_profiled_f32(const pope_vit_weights* w, const float* img, int B, int H, int W, const float* posb,
-                                  float* x_prenorm, float* x_norm, void* workspace, size_t workspace_bytes,
-                                  void* stream, void* const* events_host, int n_events, int* kinds_host,
-                                  int* n_launches_host) {
-    return pope_vit_forward_profiled_mask_f32(w, img, B, H, W, posb, x_prenorm, x_norm, workspace, workspace_bytes, stream,
-                                              events_host, n_events, kinds_host, n_launches_host, ~0u);
 }
 
 int pope_vit_launch_count(int depth) { return depth > 0 ? 7 * depth + 2 : 0; }
@@ -387,13 +383,14 @@ int pope_dense_match_f32(const float* feat0, long long stride0, const float* fea
                          float* mkpts1_c, int* counts, void* workspace, size_t workspace_bytes, void* stream) {
     return pope_dense_match_prec_f32(feat0, stride0, feat1, stride1, n, L, S, C, h0, w0, h1, w1, thr, border_rm, temperature, scale,
                                      conf_matrix, b_ids, i_ids, j_ids, mconf, mkpts0_c, mkpts1_c, counts, workspace,
-                                     workspace_bytes, POPE_PREC_F32_MFMA, stream);
+                                     workspace_bytes, POPE_PREC_F32_MFMA, nullptr, stream);
 }
 
 int pope_dense_match_prec_f32(const float* feat0, long long stride0, const float* feat1, long long stride1, int n, int L,
                               int S, int C, int h0, int w0, int h1, int w1, float thr, int border_rm, float temperature, float scale, float* conf_matrix,
                               long long* b_ids, long long* i_ids, long long* j_ids, float* mconf, float* mkpts0_c,
-                              float* mkpts1_c, int* counts, void* workspace, size_t workspace_bytes, int precision, void* stream) {
+                              float* mkpts1_c, int* counts, void* workspace, size_t workspace_bytes, int precision,
+                              unsigned* range_flag, void* stream) {
     StreamDevice on_device(stream);
     if (!feat0 || !feat1 || !conf_matrix || !b_ids || !i_ids || !j_ids || !mconf || !mkpts0_c || !mkpts1_c ||
         !counts || !workspace)
@@ -422,6 +419,7 @@ int pope_dense_match_prec_f32(const float* feat0, long long stride0, const float
         p.planes1 = ws + 5 * nl + 3 * ns + align_up(size_t(n) * L * C * 4, 256);
     }
     p.counts = counts;
+    p.range_flag = range_flag;
     p.b_ids = b_ids; p.i_ids = i_ids; p.j_ids = j_ids;
     p.mconf = mconf; p.mkpts0 = mkpts0_c; p.mkpts1 = mkpts1_c;
     return pope_launch_dense_match_f32(p, static_cast<hipStream_t>(stream));

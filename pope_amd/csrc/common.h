@@ -79,6 +79,23 @@ static inline bool pope_opt_in_lds(K kernel, size_t bytes, pope_dev_mask& done) 
     return true;
 }
 
+// ---- f16x3 range guard ------------------------------------------------------------------------------------------
+// A planes producer converts value * scale to f16; a finite fp32 value whose scaled magnitude reaches 65520 rounds
+// to +-inf there (and poisons everything downstream) although the fp32 reference is fine.  Every producer therefore
+// tracks the largest scaled magnitude it converts and ORs its POPE_RANGE_* bit into a caller-provided device word;
+// the host checks the word at its next synchronisation point and re-runs the work on the fp32 MFMA.
+constexpr float POPE_F16_OVERFLOW = 65520.0f;  // smallest magnitude that RNE-rounds to f16 infinity
+__device__ __forceinline__ void pope_range_flag(unsigned* flag, unsigned bit, bool bad) {
+    if (flag && bad) (void)__hip_atomic_fetch_or(flag, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float pope_amax4(float m, f32x4 v) {
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])),
+                           __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])), m));
+}
+__device__ __forceinline__ float pope_amax2(float m, f32x2 v) {
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), m);
+}
+
 static inline int pope_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? POPE_OK : POPE_ERR_LAUNCH;

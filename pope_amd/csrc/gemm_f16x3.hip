@@ -415,6 +415,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
         }
         __syncthreads();  // all waves have finished reading the last K-step stage
         float* E = epi + wave * 32 * EPI_ST2;
+        float amax = 0.f;  // OUT_PLANES: largest magnitude written as planes (range guard)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -452,6 +453,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
                     }
                     if constexpr (OUT_PLANES) {
                         f16x4 hi, lo;
+                        amax = pope_amax4(amax, v);
                         split(v, A_SCALE, hi, lo);
                         const unsigned o = col_ok[ni] ? off + unsigned((col[ni] >> 5) * 128 + (col[ni] & 31) * 2) : DROP;
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rc, o, 0, 2);
@@ -464,6 +466,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+        if constexpr (OUT_PLANES) pope_range_flag(g.range_flag, g.range_bit, !(amax * A_SCALE < POPE_F16_OVERFLOW));
         __syncthreads();  // epilogue staging is drained before the stage is written again
     };
     auto epilogue = [&](int tile, float* epi) {
@@ -546,6 +549,8 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
         constexpr unsigned DROP = 0xFFFFFF00u;  // beyond every buffer extent: the access is discarded
         __syncthreads();  // all waves have finished reading the last K-step stage
         float* E = epi + wave * 32 * EPI_ST;
+        float amax = 0.f;  // OUT_PLANES: largest magnitude written as planes (range guard; rows >= M hold finite junk
+                           // computed from zero-filled operands: bias / gelu(bias), the same values as real rows see)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -583,6 +588,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
                 }
                 if constexpr (OUT_PLANES) {
                     f16x4 hi, lo;
+                    amax = pope_amax4(amax, v);
                     split(v, A_SCALE, hi, lo);
                     // planes row: per 32-column chunk [32 hi | 32 lo] halves.  (Trading halves between neighbouring
                     // lanes so that each lane issues one 16-byte store — even lanes hi, odd lanes lo — was 6 % slower.)
@@ -604,6 +610,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
             }
             __builtin_amdgcn_wave_barrier();
         }
+        if constexpr (OUT_PLANES) pope_range_flag(g.range_flag, g.range_bit, !(amax * A_SCALE < POPE_F16_OVERFLOW));
         __syncthreads();  // epilogue staging is drained before the stage is written again
     };
 
@@ -800,6 +807,12 @@ bool pope_gemm_f16x3_supported(const GemmParams& g) {
 
 int pope_launch_gemm_nt_f16x3(const GemmParams& g, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.N & 3) || (g.ldc & 3) || !pope_gemm_f16x3_supported(g)) return POPE_ERR_ARG;
+    if (g.range_flag) {  // this kernel splits fp32 operands inside its K loop: check them in a scan of their own
+        if (g.lda != g.K || g.ldw != g.K) return POPE_ERR_ARG;
+        int rc = pope_launch_range_check(g.A, size_t(g.M) * g.K, A_SCALE, g.range_flag, POPE_RANGE_INPUT, stream);
+        if (!rc) rc = pope_launch_range_check(g.W, size_t(g.N) * g.K, W_SCALE, g.range_flag, POPE_RANGE_INPUT, stream);
+        if (rc) return rc;
+    }
     if ((g.lda & 3) || (g.ldw & 3) || (reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(g.W) & 15) ||
         (reinterpret_cast<uintptr_t>(g.C) & 15))
         return POPE_ERR_ARG;

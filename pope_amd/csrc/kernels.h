@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "../../include/pope_hip.h"  // POPE_RANGE_* bits of the f16x3 range-guard word
 
 enum GemmEpilogue {
     EPI_BIAS = 0,         // C = A.W^T + bias
@@ -36,6 +37,10 @@ struct GemmParams {
     const void* a_pl;
     const void* w_pl;
     void* c_pl;
+    // f16x3 range guard: a planes-writing epilogue ORs range_bit into *range_flag (may be null) when a value does
+    // not fit f16 after scaling; the on-the-fly f16x3 kernel checks its operands before the split
+    unsigned* range_flag;
+    unsigned range_bit;
     // patch-embed gather (EPI_POSB)
     const float* posb;   // [ntok, N]: row 0 = cls_token + pos[0]; row n = conv bias + pos[n]
     int ntok, img_h, img_w, patch, grid_w;
@@ -52,16 +57,20 @@ constexpr float K_PLANES_ACT_SCALE = 8.0f, K_PLANES_W_SCALE = 256.0f;  // == POP
 
 // y = LayerNorm(x) written as f16 planes (scale POPE_PLANES_ACT_SCALE), [rows, dim] halves each.
 int pope_launch_layernorm_planes(const float* x, int ldx, const float* w, const float* b, void* y_pl,
-                                 int rows, int dim, float eps, hipStream_t stream);
+                                 int rows, int dim, float eps, unsigned* range_flag, hipStream_t stream);
 // Generic fp32 [rows, ld] -> planes converter (ld % 32 == 0).
 // patch embed, f16x3: image [B,3,H,W] -> A planes [B*ntok, kp] (kp = 3*patch^2 rounded up to 32; row b*ntok is the
 // all-zero CLS row, row b*ntok + 1 + n the flattened patch n; zero K padding)
-int pope_launch_im2col_planes(const float* img, void* a_planes, int B, int H, int W, int patch, int kp, hipStream_t stream);
+int pope_launch_im2col_planes(const float* img, void* a_planes, int B, int H, int W, int patch, int kp, unsigned* range_flag,
+                              hipStream_t stream);
 // matcher operand: planes of feat / divisor (a true fp32 division, coarse_matching.py:109) for n blocks of `rows` rows
 // with `bs` elements between blocks; output compact [n*rows, cols]
 int pope_launch_div_planes(const float* src, long long bs, void* planes, int n, int rows, int cols, float divisor, float scale,
-                           hipStream_t stream);
-int pope_launch_split_planes(const float* src, void* pl, int rows, int ld, float scale, hipStream_t stream);
+                           unsigned* range_flag, hipStream_t stream);
+int pope_launch_split_planes(const float* src, void* pl, int rows, int ld, float scale, unsigned* range_flag, hipStream_t stream);
+// HBM-bound scan: ORs `bit` into *flag when any |x[i]| * scale >= 65520 or x[i] is not finite (operand check of the
+// op-level f16x3 entry points, which split fp32 operands inside their K loops)
+int pope_launch_range_check(const float* x, size_t n, float scale, unsigned* flag, unsigned bit, hipStream_t stream);
 int pope_launch_gemm_nt_f16x3(const GemmParams& g, hipStream_t stream);
 
 // y[r,:] = LayerNorm(x[r,:]) * w + b over `dim` (multiple of 128, <= 2048), eps inside the sqrt.
@@ -93,6 +102,7 @@ struct MatchParams {
     float* conf_rowmax;              // [n, L]
     int* row_j;                      // [n, L]  matched column or -1
     float* row_conf;                 // [n, L]
+    unsigned* range_flag;            // optional f16x3 range-guard word (POPE_RANGE_MATCH)
     int* counts;                     // [n + 1] per-pair match counts, then total
     // compacted outputs (capacity n * L)
     long long* b_ids; long long* i_ids; long long* j_ids;

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __re
                                                                 const float* __restrict__ w,
                                                                 const float* __restrict__ b,
                                                                 _Float16* __restrict__ ypl,
-                                                                int rows, float eps, float scale) {
+                                                                int rows, float eps, float scale, unsigned* flag) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __re
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
     _Float16* yr = ypl + size_t(row) * (2 * NV * 128);  // planes layout: per 32-column chunk [32 hi | 32 lo]
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 128 + lane * 2;
@@ -85,11 +86,14 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __re
         f32x2 y;
         y[0] = ((v[i][0] - mean) * rstd * ww[0] + bb[0]) * scale;
         y[1] = ((v[i][1] - mean) * rstd * ww[1] + bb[1]) * scale;
+        amax = pope_amax2(amax, y);
         const f16x2 hi = __builtin_convertvector(y, f16x2);
         const f16x2 lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x2), f16x2);
         *reinterpret_cast<f16x2*>(yr + (c >> 5) * 64 + (c & 31)) = hi;
         *reinterpret_cast<f16x2*>(yr + (c >> 5) * 64 + 32 + (c & 31)) = lo;
     }
+    // a non-finite row (inf / NaN from an earlier overflow) has a non-finite mean or rstd; fmax ignores NaN
+    pope_range_flag(flag, POPE_RANGE_LAYERNORM, !(amax < POPE_F16_OVERFLOW) || !(__builtin_fabsf(mean) + rstd < INFINITY));
 }
 
 // Same, two rows per wave (one per 32-lane half), 16-byte loads: dim = NV4 * 128 <= 512.  The 8-byte loads of the
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void layernorm_planes_half_kernel(const float*
                                                                      const float* __restrict__ w,
                                                                      const float* __restrict__ b,
                                                                      _Float16* __restrict__ ypl, int rows, float eps,
-                                                                     float scale) {
+                                                                     float scale, unsigned* flag) {
     const int l = threadIdx.x & 31;
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
     const bool live = row < rows;
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(256) void layernorm_planes_half_kernel(const float*
     const float rstd = 1.0f / sqrtf(half_sum(q) * inv_d + eps);
     if (!live) return;
     _Float16* yr = ypl + size_t(row) * (2 * NV4 * 128);
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         const int c = i * 128 + l * 4;
@@ -138,48 +143,62 @@ __global__ __launch_bounds__(256) void layernorm_planes_half_kernel(const float*
         f32x4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = ((v[i][e] - mean) * rstd * ww[e] + bb[e]) * scale;
+        amax = pope_amax4(amax, y);
         const f16x4_ln hi = __builtin_convertvector(y, f16x4_ln);
         const f16x4_ln lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x4), f16x4_ln);
         *reinterpret_cast<f16x4_ln*>(yr + (c >> 5) * 64 + (c & 31)) = hi;
         *reinterpret_cast<f16x4_ln*>(yr + (c >> 5) * 64 + 32 + (c & 31)) = lo;
     }
+    pope_range_flag(flag, POPE_RANGE_LAYERNORM, !(amax < POPE_F16_OVERFLOW) || !(__builtin_fabsf(mean) + rstd < INFINITY));
 }
 
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, _Float16* __restrict__ pl,
-                                                            size_t n2, int ld, float scale) {
+                                                            size_t n2, int ld, float scale, unsigned* flag) {
+    float amax = 0.f;
+    bool nonfinite = false;
     for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n2; i += size_t(gridDim.x) * 256) {
         const size_t e = 2 * i, row = e / ld;
         const int c = int(e - row * ld);
         const f32x2 y = *reinterpret_cast<const f32x2*>(src + e) * scale;
+        amax = pope_amax2(amax, y);
+        nonfinite |= !(y[0] + y[1] == y[0] + y[1]);
         const f16x2 h = __builtin_convertvector(y, f16x2);
         _Float16* o = pl + row * 2 * ld + (c >> 5) * 64 + (c & 31);
         *reinterpret_cast<f16x2*>(o) = h;
         *reinterpret_cast<f16x2*>(o + 32) = __builtin_convertvector(y - __builtin_convertvector(h, f32x2), f16x2);
     }
+    pope_range_flag(flag, POPE_RANGE_INPUT, nonfinite || !(amax < POPE_F16_OVERFLOW));
 }
 
 __global__ __launch_bounds__(256) void div_planes_kernel(const float* __restrict__ src, long long bs, _Float16* __restrict__ pl,
-                                                          int n, int rows, int cols, float divisor, float scale) {
+                                                          int n, int rows, int cols, float divisor, float scale, unsigned* flag) {
     const size_t per = size_t(rows) * cols / 2, n2 = per * n;
+    float amax = 0.f;
+    bool nonfinite = false;
     for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n2; i += size_t(gridDim.x) * 256) {
         const size_t b = i / per, e = (i - b * per) * 2, row = e / cols;
         const int c = int(e - row * cols);
         f32x2 y = *reinterpret_cast<const f32x2*>(src + b * bs + e);
         y[0] = (y[0] / divisor) * scale;   // the division first, exactly as the reference rounds it; scale is a power of two
         y[1] = (y[1] / divisor) * scale;
+        amax = pope_amax2(amax, y);
+        nonfinite |= !(y[0] + y[1] == y[0] + y[1]);
         const f16x2 hi = __builtin_convertvector(y, f16x2);
         _Float16* o = pl + (b * rows + row) * 2 * cols + (c >> 5) * 64 + (c & 31);
         *reinterpret_cast<f16x2*>(o) = hi;
         *reinterpret_cast<f16x2*>(o + 32) = __builtin_convertvector(y - __builtin_convertvector(hi, f32x2), f16x2);
     }
+    pope_range_flag(flag, POPE_RANGE_MATCH, nonfinite || !(amax < POPE_F16_OVERFLOW));
 }
 
 // Patch embed operand: one thread per (row, k pair).  Row b*ntok + 1 + (py*gw + px), k = c*p*p + dy*p + dx reads
 // img[b, c, py*p + dy, px*p + dx] (patch_embed.py:69-82: Conv2d with kernel = stride = patch, flattened row-major).
 __global__ __launch_bounds__(256) void im2col_planes_kernel(const float* __restrict__ img, _Float16* __restrict__ pl,
-                                                             int B, int H, int W, int patch, int kp, int ntok, int gw) {
+                                                             int B, int H, int W, int patch, int kp, int ntok, int gw, unsigned* flag) {
     const size_t n2 = size_t(B) * ntok * (kp / 2);
     const int k_real = 3 * patch * patch, pp = patch * patch;
+    float amax = 0.f;
+    bool nonfinite = false;
     for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n2; i += size_t(gridDim.x) * 256) {
         const size_t row = i / (kp / 2);
         const int k = int(i - row * (kp / 2)) * 2;
@@ -197,47 +216,70 @@ __global__ __launch_bounds__(256) void im2col_planes_kernel(const float* __restr
             }
         }
         v = v * K_PLANES_ACT_SCALE;
+        amax = pope_amax2(amax, v);
+        nonfinite |= !(v[0] + v[1] == v[0] + v[1]);
         const f16x2 hi = __builtin_convertvector(v, f16x2);
         _Float16* o = pl + row * 2 * kp + (k >> 5) * 64 + (k & 31);
         *reinterpret_cast<f16x2*>(o) = hi;
         *reinterpret_cast<f16x2*>(o + 32) = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
     }
+    pope_range_flag(flag, POPE_RANGE_PATCH, nonfinite || !(amax < POPE_F16_OVERFLOW));
+}
+
+__global__ __launch_bounds__(256) void range_check_kernel(const float* __restrict__ x, size_t n, float scale, unsigned* flag,
+                                                           unsigned bit) {
+    float amax = 0.f;
+    bool nonfinite = false;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) {
+        const float v = x[i] * scale;
+        amax = __builtin_fmaxf(amax, __builtin_fabsf(v));
+        nonfinite |= !(v == v);
+    }
+    pope_range_flag(flag, bit, nonfinite || !(amax < POPE_F16_OVERFLOW));
 }
 
 }  // namespace
 
+int pope_launch_range_check(const float* x, size_t n, float scale, unsigned* flag, unsigned bit, hipStream_t stream) {
+    if (!x || !flag || !n) return POPE_ERR_ARG;
+    const unsigned blocks = unsigned(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096);
+    hipLaunchKernelGGL(range_check_kernel, dim3(blocks), dim3(256), 0, stream, x, n, scale, flag, bit);
+    return pope_check_launch();
+}
+
 int pope_launch_div_planes(const float* src, long long bs, void* planes, int n, int rows, int cols, float divisor, float scale,
-                           hipStream_t stream) {
+                           unsigned* flag, hipStream_t stream) {
     if (!src || !planes || n <= 0 || rows <= 0 || cols <= 0 || (cols & 31) || (bs & 1) || bs < (long long)rows * cols) return POPE_ERR_ARG;
     const size_t n2 = size_t(n) * rows * cols / 2;
     const unsigned blocks = unsigned(n2 / 256 + 1 < 65536 ? n2 / 256 + 1 : 65536);
     hipLaunchKernelGGL(div_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, bs, static_cast<_Float16*>(planes), n, rows,
-                       cols, divisor, scale);
+                       cols, divisor, scale, flag);
     return pope_check_launch();
 }
 
-int pope_launch_im2col_planes(const float* img, void* a_planes, int B, int H, int W, int patch, int kp, hipStream_t stream) {
+int pope_launch_im2col_planes(const float* img, void* a_planes, int B, int H, int W, int patch, int kp, unsigned* flag,
+                              hipStream_t stream) {
     if (!img || !a_planes || B <= 0 || patch <= 0 || H % patch || W % patch || (kp & 31) || kp < 3 * patch * patch) return POPE_ERR_ARG;
     const int gw = W / patch, ntok = 1 + (H / patch) * gw;
     const size_t n2 = size_t(B) * ntok * (kp / 2);
     const unsigned blocks = unsigned(n2 / 256 + 1 < 65536 ? n2 / 256 + 1 : 65536);
     hipLaunchKernelGGL(im2col_planes_kernel, dim3(blocks), dim3(256), 0, stream, img, static_cast<_Float16*>(a_planes), B, H, W,
-                       patch, kp, ntok, gw);
+                       patch, kp, ntok, gw, flag);
     return pope_check_launch();
 }
 
 int pope_launch_layernorm_planes(const float* x, int ldx, const float* w, const float* b, void* y_pl,
-                                 int rows, int dim, float eps, hipStream_t stream) {
+                                 int rows, int dim, float eps, unsigned* flag, hipStream_t stream) {
     if (rows <= 0 || dim <= 0 || (dim & 127) || dim > 2048 || (ldx & 1) || !y_pl) return POPE_ERR_ARG;
     _Float16* ypl = static_cast<_Float16*>(y_pl);
     if (dim <= 512 && !(ldx & 3) && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(w) & 15) &&
         !(reinterpret_cast<uintptr_t>(b) & 15)) {  // two rows per wave, 16-byte accesses
         const dim3 g8((rows + 7) / 8), b256(256);
         switch (dim / 128) {
-            case 1: hipLaunchKernelGGL(layernorm_planes_half_kernel<1>, g8, b256, 0, stream, x, ldx, w, b, ypl, rows, eps, K_PLANES_ACT_SCALE); break;
-            case 2: hipLaunchKernelGGL(layernorm_planes_half_kernel<2>, g8, b256, 0, stream, x, ldx, w, b, ypl, rows, eps, K_PLANES_ACT_SCALE); break;
-            case 3: hipLaunchKernelGGL(layernorm_planes_half_kernel<3>, g8, b256, 0, stream, x, ldx, w, b, ypl, rows, eps, K_PLANES_ACT_SCALE); break;
-            default: hipLaunchKernelGGL(layernorm_planes_half_kernel<4>, g8, b256, 0, stream, x, ldx, w, b, ypl, rows, eps, K_PLANES_ACT_SCALE); break;
+            case 1: hipLaunchKernelGGL(layernorm_planes_half_kernel<1>, g8, b256, 0, stream, x, ldx, w, b, ypl, rows, eps, K_PLANES_ACT_SCALE, flag); break;
+            case 2: hipLaunchKernelGGL(layernorm_planes_half_kernel<2>, g8, b256, 0, stream, x, ldx, w, b, ypl, rows, eps, K_PLANES_ACT_SCALE, flag); break;
+            case 3: hipLaunchKernelGGL(layernorm_planes_half_kernel<3>, g8, b256, 0, stream, x, ldx, w, b, ypl, rows, eps, K_PLANES_ACT_SCALE, flag); break;
+            default: hipLaunchKernelGGL(layernorm_planes_half_kernel<4>, g8, b256, 0, stream, x, ldx, w, b, ypl, rows, eps, K_PLANES_ACT_SCALE, flag); break;
         }
         return pope_check_launch();
     }
@@ -245,7 +287,7 @@ int pope_launch_layernorm_planes(const float* x, int ldx, const float* w, const 
 #define POPE_LNP_CASE(NV)                                                                                    \
     case NV:                                                                                                 \
         hipLaunchKernelGGL(layernorm_planes_kernel<NV>, grid, block, 0, stream, x, ldx, w, b, ypl, rows, eps,    \
-                           K_PLANES_ACT_SCALE);                                                           \
+                           K_PLANES_ACT_SCALE, flag);                                                     \
         break;
     switch (dim / 128) {
         POPE_LNP_CASE(1) POPE_LNP_CASE(2) POPE_LNP_CASE(3) POPE_LNP_CASE(4) POPE_LNP_CASE(6) POPE_LNP_CASE(8)
@@ -256,11 +298,11 @@ int pope_launch_layernorm_planes(const float* x, int ldx, const float* w, const 
     return pope_check_launch();
 }
 
-int pope_launch_split_planes(const float* src, void* pl, int rows, int ld, float scale, hipStream_t stream) {
+int pope_launch_split_planes(const float* src, void* pl, int rows, int ld, float scale, unsigned* flag, hipStream_t stream) {
     if (!src || !pl || rows <= 0 || ld <= 0 || (ld & 31)) return POPE_ERR_ARG;
     const size_t n2 = size_t(rows) * ld / 2;
     const unsigned blocks = unsigned(n2 / 256 + 1 < 4096 ? n2 / 256 + 1 : 4096);
-    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, static_cast<_Float16*>(pl), n2, ld, scale);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, src, static_cast<_Float16*>(pl), n2, ld, scale, flag);
     return pope_check_launch();
 }
 

@@ -237,8 +237,8 @@ int pope_launch_dense_match_f32(const MatchParams& p, hipStream_t stream) {
     if (p.planes0 && p.planes1 && (p.C & 31) == 0 && p.C >= 64) {
         // f16x3: (f0 / sqrt(C)) and (f1 / sqrt(C)) as hi/lo planes (x256), one batched planes GEMM, (acc / 2^16) / T
         const float norm = sqrtf(float(p.C));
-        int rc = pope_launch_div_planes(p.feat0, p.bs0, p.planes0, p.n, p.L, p.C, norm, K_PLANES_W_SCALE, stream);
-        if (!rc) rc = pope_launch_div_planes(p.feat1, p.bs1, p.planes1, p.n, p.S, p.C, norm, K_PLANES_W_SCALE, stream);
+        int rc = pope_launch_div_planes(p.feat0, p.bs0, p.planes0, p.n, p.L, p.C, norm, K_PLANES_W_SCALE, p.range_flag, stream);
+        if (!rc) rc = pope_launch_div_planes(p.feat1, p.bs1, p.planes1, p.n, p.S, p.C, norm, K_PLANES_W_SCALE, p.range_flag, stream);
         if (rc) return rc;
         GemmParams g = {};
         g.a_pl = p.planes0; g.w_pl = p.planes1; g.C = p.sim;

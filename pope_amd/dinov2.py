@@ -4,14 +4,22 @@ Same constructor arguments, attribute names, state-dict keys (175 for ViT-S/14, 
 ``strict=True`` from a reference checkpoint) and call surface as
 ``dinov2/dinov2/models/vision_transformer.py:45-295`` — ``model(x)``, ``model(x, is_training=True)``,
 ``forward_features``, ``get_intermediate_layers`` — but the forward pass is ONE call into the HIP
-library (``pope_vit_forward_f32``): patch-embed GEMM (+cls +pos), 12 x [LN, QKV GEMM, flash
+library (``pope_vit_forward_f32``): patch-embed GEMM (+cls +pos), depth x [LN, QKV GEMM, flash
 attention, proj GEMM + LayerScale + residual, LN, FC1 GEMM + GELU, FC2 GEMM + LayerScale +
-residual], final LN — all hand-written gfx950 kernels on the fp32 MFMA.
+residual], final LN — all hand-written gfx950 kernels.  fp32 in HBM, fp32 accumulation; the contractions
+run in ``model.precision``: "f16x3" (default: operands as f16 hi+lo pairs on the f16 matrix cores, three
+MFMAs per product) or "f32" (fp32-in MFMA).
+
+f16x3 has a range contract (|activation| < 8190, |weight| < 255.9, pope_hip.h) and it is guarded: weights
+are checked when their planes are built, activations by the kernels that convert them (a device flag read
+after the launch sequence).  ``model.on_overflow`` says what happens then: "rerun_f32" (default: warn once
+and run that call again on the fp32 MFMA, in the same process) or "raise" (``PopeRangeError``).
 
 torch.nn modules are used here only as parameter containers (so ``.to()``, ``.eval()``,
 ``state_dict()`` behave like the reference); they are never called.  There is no CPU fallback:
 calling the model on CPU tensors raises.
 """
+import warnings
 import ctypes as C
 import math
 from functools import partial
@@ -21,7 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from ._lib import check, ptr, require_cuda, stream_of
+from ._lib import PopeRangeError, check, on_device_of, ptr, require_cuda, stream_of
 
 
 DEFAULT_PRECISION = "f16x3"
@@ -105,11 +113,13 @@ class DinoVisionTransformer(nn.Module):
         self.head = nn.Identity()
         self.mask_token = nn.Parameter(torch.zeros(1, embed_dim))
         self.init_weights()
-        self._wcache = None
+        self._wcache = {}
         self._posb_cache = {}
         self._ws = None
         self.profiler = None  # optional pope_amd.profiling.KernelProfiler (in-situ kernel timing)
         self.precision = DEFAULT_PRECISION  # arithmetic of the Linear layers: "f16x3" or "f32" (_lib.PRECISIONS)
+        self.on_overflow = "rerun_f32"      # f16x3 range guard policy: "rerun_f32" | "raise"
+        self.overflow_events = 0            # calls that left the f16x3 range (and were re-run or raised)
         for p in self.parameters():
             p.requires_grad_(False)  # inference-only kernels
 
@@ -125,18 +135,37 @@ class DinoVisionTransformer(nn.Module):
     # ---- cache management ----------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
-        self._wcache, self._posb_cache, self._ws = None, {}, None
+        self._wcache, self._posb_cache, self._ws = {}, {}, None
         return out
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
-        self._wcache, self._posb_cache = None, {}
+        self._wcache, self._posb_cache = {}, {}
         return out
 
-    def _weights(self):
+    def _weights(self, precision=None):
+        """ctypes weight struct of one arithmetic mode (cached per mode: the fp32 re-run of the range guard does not
+        evict the f16x3 planes).  f16x3: the Linear / patch-embed weights as hi/lo planes, after a range check —
+        |w| * 256 must be finite in f16; a checkpoint that breaches it runs on the fp32 MFMA (or raises)."""
+        precision = precision or self.precision
         dev_ptr = self.cls_token.data_ptr()
-        if self._wcache is not None and self._wcache[0] == dev_ptr and self._wcache[4] == self.precision:
-            return self._wcache[1]
+        hit = self._wcache.get(precision)
+        if hit is not None and hit[0] == dev_ptr:
+            return hit[1]
+        if precision == "f16x3":
+            lin = [self.patch_embed.proj.weight] + [t for b in self.blocks for t in
+                                                    (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.fc1.weight, b.mlp.fc2.weight)]
+            amax = float(torch.stack([t.detach().abs().max() for t in lin]).max())
+            if not amax * _lib.PLANES_W_SCALE < _lib.F16_MAX:   # also catches NaN
+                self.overflow_events += 1
+                msg = (f"pope_amd: max |weight| = {amax:g} is outside the f16x3 range contract "
+                       f"(|w| < {_lib.F16_MAX / _lib.PLANES_W_SCALE:g})")
+                if self.on_overflow == "raise":
+                    raise PopeRangeError(msg)
+                warnings.warn(msg + "; this model runs with precision='f32'")
+                w = self._weights("f32")
+                self._wcache["f16x3"] = self._wcache["f32"]
+                return w
         tensors = []
 
         def P(t):
@@ -149,7 +178,7 @@ class DinoVisionTransformer(nn.Module):
 
         def planes(wt):
             """f16 hi/lo planes of a Linear weight for the f16x3 GEMM (layout: pope_hip.h)."""
-            if self.precision != "f16x3" or not wt.is_cuda or wt.shape[1] % 32:
+            if precision != "f16x3" or not wt.is_cuda or wt.shape[1] % 32:
                 return None
             pl = _lib.to_planes(wt, _lib.PLANES_W_SCALE)
             tensors.append(pl)
@@ -165,13 +194,13 @@ class DinoVisionTransformer(nn.Module):
                 planes(b.attn.proj.weight))
         pw = self.patch_embed.proj.weight.detach().reshape(self.embed_dim, -1)
         patch_wp = None
-        if self.precision == "f16x3" and pw.is_cuda:   # [dim, 3*p*p] zero-padded to a multiple of 32 columns
+        if precision == "f16x3" and pw.is_cuda:   # [dim, 3*p*p] zero-padded to a multiple of 32 columns
             kp = (pw.shape[1] + 31) // 32 * 32
             patch_wp = planes(torch.nn.functional.pad(pw.float(), (0, kp - pw.shape[1])))
         w = _lib.VitWeights(self.embed_dim, self.n_blocks, self.num_heads, self.patch_size,
                             self.blocks[0].mlp.fc1.weight.shape[0], P(pw),
-                            P(self.norm.weight), P(self.norm.bias), blocks, _lib.PRECISIONS[self.precision], patch_wp)
-        self._wcache = (dev_ptr, w, blocks, tensors, self.precision)
+                            P(self.norm.weight), P(self.norm.bias), blocks, _lib.PRECISIONS[precision], patch_wp)
+        self._wcache[precision] = (dev_ptr, w, blocks, tensors)
         return w
 
     # ---- positional encoding (host plumbing, cached per (H, W)) -----------------------------
@@ -217,7 +246,12 @@ class DinoVisionTransformer(nn.Module):
         return ws
 
     # ---- forward --------------------------------------------------------------------------
-    def _run(self, x, taps=(), out_norm=None):
+    def _run(self, x, taps=(), out_norm=None, range_flag=None, precision=None):
+        """One launch sequence (or several, for batches beyond the 32-bit offsets).  `range_flag`: int32[1] device
+        tensor owned by the caller, who then checks it at a synchronisation point of its own (PairPipeline does);
+        without it this call reads its own flag right after the launches — the one host synchronisation of a
+        direct call, where the reference's callers synchronise anyway (`.item()` / `.cpu()` per proposal,
+        eval_linemod_json.py:95,115) — and applies `self.on_overflow`."""
         require_cuda(x, "DinoVisionTransformer.forward")
         require_cuda(self.cls_token, "DinoVisionTransformer weights")
         if x.dtype != torch.float32:
@@ -229,6 +263,7 @@ class DinoVisionTransformer(nn.Module):
         assert W % p == 0, f"Input image width {W} is not a multiple of patch width: {p}"
         ntok = 1 + (H // p) * (W // p)
         dim = self.embed_dim
+        precision = precision or self.precision
         # The kernels address a launch sequence's activations through 32-bit byte offsets: larger batches are run as
         # several sequences writing into slices of the same outputs (identical results: images are independent).
         widest = max(4 * dim, int(self.blocks[0].mlp.fc1.weight.shape[0]))
@@ -239,41 +274,65 @@ class DinoVisionTransformer(nn.Module):
             x_norm = out_norm if out_norm is not None else torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32)
             tap_out = [torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32) for _ in taps]
             for s in range(0, B, max_b):
-                pre_s, _, taps_s = self._run(x[s:s + max_b], taps, out_norm=x_norm[s:s + max_b])
+                pre_s, _, taps_s = self._run(x[s:s + max_b], taps, out_norm=x_norm[s:s + max_b], range_flag=range_flag,
+                                             precision=precision)
                 x_pre[s:s + max_b] = pre_s
                 for dst, src in zip(tap_out, taps_s):
                     dst[s:s + max_b] = src
             return x_pre, x_norm, tap_out
-        w = self._weights()
-        posb = self._posb(H, W, ntok)
-        L = _lib.lib()
-        nbytes = L.pope_vit_workspace_bytes(B, ntok, dim, w.hidden)
-        ws = self._workspace(nbytes, x.device)
-        x_pre = torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32)
-        if out_norm is None:
-            x_norm = torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32)
-        else:  # caller-provided destination (a batch slice of a larger buffer: no concatenation afterwards)
-            if out_norm.shape != (B, ntok, dim) or out_norm.dtype != torch.float32 or not out_norm.is_contiguous() \
-                    or out_norm.device != x.device:
-                raise ValueError("out_norm must be a contiguous float32 [B, ntok, dim] tensor on the input's device")
-            x_norm = out_norm
-        tap_out = [torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32) for _ in taps]
-        tap_blocks = (C.c_int * max(1, len(taps)))(*taps)
-        tap_ptrs = (C.c_void_p * max(1, len(taps)))(*[t.data_ptr() for t in tap_out])
-        slot = self.profiler.next_slot() if (self.profiler is not None and not taps) else None
-        if slot is not None:
-            off, ev, cap, kinds = slot
-            n_launch = C.c_int()
-            check(L.pope_vit_forward_profiled_mask_f32(C.byref(w), ptr(x), B, H, W, ptr(posb), ptr(x_pre), ptr(x_norm),
-                                                       C.c_void_p(ws.data_ptr()), ws.numel(), stream_of(x.device), ev,
-                                                       cap, kinds, C.byref(n_launch), self.profiler.mask),
-                  "pope_vit_forward_profiled_mask_f32")
-            self.profiler.commit(off, n_launch.value)
-            return x_pre, x_norm, tap_out
-        check(L.pope_vit_forward_f32(C.byref(w), ptr(x), B, H, W, ptr(posb), ptr(x_pre), ptr(x_norm),
-                                     len(taps), tap_blocks, tap_ptrs, C.c_void_p(ws.data_ptr()), ws.numel(),
-                                     stream_of(x.device)), "pope_vit_forward_f32")
+        with on_device_of(x):
+            w = self._weights(precision)
+            guarded = w.precision == _lib.PREC_F16X3
+            own_flag = None
+            if guarded and range_flag is None:
+                own_flag = range_flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+            flag_ptr = C.c_void_p(range_flag.data_ptr()) if (guarded and range_flag is not None) else None
+            posb = self._posb(H, W, ntok)
+            L = _lib.lib()
+            nbytes = L.pope_vit_workspace_bytes(B, ntok, dim, w.hidden)
+            ws = self._workspace(nbytes, x.device)
+            x_pre = torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32)
+            if out_norm is None:
+                x_norm = torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32)
+            else:  # caller-provided destination (a batch slice of a larger buffer: no concatenation afterwards)
+                if out_norm.shape != (B, ntok, dim) or out_norm.dtype != torch.float32 or not out_norm.is_contiguous() \
+                        or out_norm.device != x.device:
+                    raise ValueError("out_norm must be a contiguous float32 [B, ntok, dim] tensor on the input's device")
+                x_norm = out_norm
+            tap_out = [torch.empty(B, ntok, dim, device=x.device, dtype=torch.float32) for _ in taps]
+            tap_blocks = (C.c_int * max(1, len(taps)))(*taps)
+            tap_ptrs = (C.c_void_p * max(1, len(taps)))(*[t.data_ptr() for t in tap_out])
+            slot = self.profiler.next_slot() if (self.profiler is not None and not taps) else None
+            if slot is not None:
+                off, ev, cap, kinds = slot
+                n_launch = C.c_int()
+                check(L.pope_vit_forward_profiled_mask_f32(C.byref(w), ptr(x), B, H, W, ptr(posb), ptr(x_pre), ptr(x_norm),
+                                                           C.c_void_p(ws.data_ptr()), ws.numel(), flag_ptr,
+                                                           stream_of(x.device), ev, cap, kinds, C.byref(n_launch),
+                                                           self.profiler.mask),
+                      "pope_vit_forward_profiled_mask_f32")
+                self.profiler.commit(off, n_launch.value)
+            else:
+                check(L.pope_vit_forward_f32(C.byref(w), ptr(x), B, H, W, ptr(posb), ptr(x_pre), ptr(x_norm),
+                                             len(taps), tap_blocks, tap_ptrs, C.c_void_p(ws.data_ptr()), ws.numel(),
+                                             flag_ptr, stream_of(x.device)), "pope_vit_forward_f32")
+        if own_flag is not None:
+            bits = int(own_flag.item())  # the direct call's synchronisation point
+            if bits:
+                self.range_overflow(bits)  # raises under on_overflow == "raise"
+                return self._run(x, taps, out_norm=out_norm, precision="f32")
         return x_pre, x_norm, tap_out
+
+    def range_overflow(self, bits):
+        """Account for a call whose activations left the f16x3 range (`bits`: POPE_RANGE_* word) and apply the policy:
+        raise, or warn (once per model) so that the caller re-runs the work with precision="f32"."""
+        self.overflow_events += 1
+        msg = (f"pope_amd: f16x3 range contract breached ({_lib.describe_range_bits(bits)}: |value| * scale "
+               f">= {_lib.F16_MAX:g} or non-finite)")
+        if self.on_overflow == "raise":
+            raise PopeRangeError(msg)
+        if self.overflow_events == 1:
+            warnings.warn(msg + "; re-running on the fp32 MFMA (precision='f32')")
 
     def prepare_tokens_with_masks(self, x, masks=None):
         """vision_transformer.py:191-200 (patch embed + cls + pos) as one HIP kernel."""
@@ -282,17 +341,27 @@ class DinoVisionTransformer(nn.Module):
         from . import ops
         B, nc, H, W = x.shape
         ntok = 1 + (H // self.patch_size) * (W // self.patch_size)
-        self._weights()
-        return ops.patch_embed(x, self.patch_embed.proj.weight.detach(), self._posb(H, W, ntok), self.patch_size,
-                               precision=self.precision)
+        require_cuda(x, "prepare_tokens_with_masks")
+        prec = "f16x3" if self._weights().precision == _lib.PREC_F16X3 else "f32"   # weight range check included
+        args = (x, self.patch_embed.proj.weight.detach(), self._posb(H, W, ntok), self.patch_size)
+        if prec == "f32":
+            return ops.patch_embed(*args, precision="f32")
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        out = ops.patch_embed(*args, precision="f16x3", range_flag=flag)
+        bits = int(flag.item())
+        if bits:
+            self.range_overflow(bits)
+            out = ops.patch_embed(*args, precision="f32")
+        return out
 
-    def forward_features(self, x, masks=None, out_norm=None):
-        """`out_norm` (extension): preallocated [B, ntok, dim] buffer that receives the final-norm tokens."""
+    def forward_features(self, x, masks=None, out_norm=None, range_flag=None, precision=None):
+        """Extensions: `out_norm` = preallocated [B, ntok, dim] buffer that receives the final-norm tokens;
+        `range_flag` / `precision`: see `_run` (deferred f16x3 range check of a batching caller)."""
         if isinstance(x, list):
             raise NotImplementedError("pope_amd: nested-tensor (list) inputs are a training-time xformers path")
         if masks is not None:
             raise NotImplementedError("pope_amd: iBOT mask tokens are training-only (out of the hot path)")
-        x_pre, x_norm, _ = self._run(x, out_norm=out_norm)
+        x_pre, x_norm, _ = self._run(x, out_norm=out_norm, range_flag=range_flag, precision=precision)
         return {"x_norm_clstoken": x_norm[:, 0], "x_norm_patchtokens": x_norm[:, 1:],
                 "x_prenorm": x_pre, "masks": masks}
 

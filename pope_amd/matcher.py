@@ -3,12 +3,13 @@
 ``dense_match`` used directly on DINOv2 patch tokens (BASELINE config 3).
 """
 import ctypes as C
+import warnings
 
 import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import check, ptr, require_cuda, stream_of
+from ._lib import PopeRangeError, check, on_device_of, ptr, require_cuda, stream_of
 
 # src/matcher/utils/cvpr_ds_config.py:10-50, lower-cased as by lower_config(); plain data.
 default_cfg = {
@@ -38,13 +39,18 @@ DEFAULT_PRECISION = "f16x3"   # arithmetic of the L x S x C contraction ("f32": 
 
 
 @torch.no_grad()
-def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, temperature=0.1, precision=None):
+def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, temperature=0.1, precision=None,
+                on_overflow="rerun_f32", want_conf=True):
     """All-pairs similarity -> dual softmax -> threshold/border/mutual-NN -> ordered matches.
 
     feat0 [n,L,C], feat1 [n,S,C] fp32 on the GPU.  Returns the dict CoarseMatching publishes
     (coarse_matching.py:145-148,239-259): conf_matrix, b_ids, i_ids, j_ids, gt_mask, m_bids,
-    mkpts0_c, mkpts1_c, mconf — plus `counts` (matches per pair, int32[n]).
-    One host synchronisation (to size the outputs), like torch.where in the reference."""
+    mkpts0_c, mkpts1_c, mconf — plus `counts` (matches per pair, int32[n]).  `want_conf=False` (batch pipelines that
+    only consume the match lists) does not publish conf_matrix.
+    One host synchronisation (to size the outputs), like torch.where in the reference.
+    precision "f16x3" (default) keeps feat / sqrt(C) * 256 as f16 pairs: the kernel that converts them guards the
+    f16 range with a device flag that travels with the match counts; on a breach the call is repeated with the
+    fp32-MFMA contraction (`on_overflow="rerun_f32"`) or raises PopeRangeError ("raise")."""
     require_cuda(feat0, "dense_match")
     require_cuda(feat1, "dense_match")
     if feat0.dtype != torch.float32 or feat1.dtype != torch.float32:
@@ -71,18 +77,28 @@ def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, tempera
     mconf = torch.empty(cap, dtype=torch.float32, device=dev)
     mk0 = torch.empty(cap, 2, dtype=torch.float32, device=dev)
     mk1 = torch.empty(cap, 2, dtype=torch.float32, device=dev)
-    counts = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    counts = torch.zeros(n + 2, dtype=torch.int32, device=dev)   # per-pair counts | total | f16x3 range-guard word
+    flag_ptr = C.c_void_p(counts.data_ptr() + 4 * (n + 1)) if precision == "f16x3" else None
     scale = hw0_i[0] / hw0_c[0]  # coarse_matching.py:242 (heights only)
-    check(lib.pope_dense_match_prec_f32(C.c_void_p(feat0.data_ptr()), feat0.stride(0), C.c_void_p(feat1.data_ptr()),
-                                        feat1.stride(0), n, L, S, Cc, h0, w0, h1, w1, float(thr), int(border_rm),
-                                        float(temperature), float(scale), ptr(conf), ptr(b_ids), ptr(i_ids), ptr(j_ids),
-                                        ptr(mconf), ptr(mk0), ptr(mk1), ptr(counts), C.c_void_p(ws.data_ptr()), ws_bytes,
-                                        prec, stream_of(dev)), "pope_dense_match_prec_f32")
+    with on_device_of(feat0):
+        check(lib.pope_dense_match_prec_f32(C.c_void_p(feat0.data_ptr()), feat0.stride(0), C.c_void_p(feat1.data_ptr()),
+                                            feat1.stride(0), n, L, S, Cc, h0, w0, h1, w1, float(thr), int(border_rm),
+                                            float(temperature), float(scale), ptr(conf), ptr(b_ids), ptr(i_ids), ptr(j_ids),
+                                            ptr(mconf), ptr(mk0), ptr(mk1), ptr(counts), C.c_void_p(ws.data_ptr()), ws_bytes,
+                                            prec, flag_ptr, stream_of(dev)), "pope_dense_match_prec_f32")
     counts_h = counts.cpu()  # sync point
+    if int(counts_h[n + 1]):   # features outside the f16x3 range: nothing of this call is valid
+        msg = (f"pope_amd: f16x3 range contract breached in dense_match ({_lib.describe_range_bits(int(counts_h[n + 1]))}: "
+               f"|feat| / sqrt(C) * {_lib.PLANES_W_SCALE:g} >= {_lib.F16_MAX:g} or non-finite)")
+        if on_overflow == "raise":
+            raise PopeRangeError(msg)
+        warnings.warn(msg + "; re-running with the fp32-MFMA contraction")
+        del conf, ws, b_ids, i_ids, j_ids, mconf, mk0, mk1
+        return dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr, border_rm, temperature, "f32", on_overflow, want_conf)
     m = int(counts_h[n])
     b_ids, i_ids, j_ids, mconf = b_ids[:m], i_ids[:m], j_ids[:m], mconf[:m]
     return {
-        "conf_matrix": conf,
+        "conf_matrix": conf if want_conf else None,
         "b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids,
         "gt_mask": mconf == 0, "m_bids": b_ids,          # eval: mconf > thr, the `!= 0` filter is a no-op
         "mkpts0_c": mk0[:m], "mkpts1_c": mk1[:m], "mconf": mconf,

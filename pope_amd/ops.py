@@ -27,9 +27,19 @@ def layernorm(x, weight, bias, eps=1e-6):
     return y
 
 
-def linear(a, weight, bias=None, epilogue=EPI_BIAS, gamma=None, res=None, out=None, precision="f32"):
+def _flag_ptr(range_flag):
+    """Device pointer of an optional int32[1] f16x3 range-guard word (pope_hip.h: range_flag)."""
+    if range_flag is None:
+        return None
+    if range_flag.dtype != torch.int32 or range_flag.numel() < 1 or not range_flag.is_cuda:
+        raise ValueError("range_flag must be an int32 CUDA tensor")
+    return C.c_void_p(range_flag.data_ptr())
+
+
+def linear(a, weight, bias=None, epilogue=EPI_BIAS, gamma=None, res=None, out=None, precision="f32", range_flag=None):
     """nn.Linear with fused epilogue: bias | bias+GELU(erf) | res + gamma*(.+bias).
-    precision: "f32" (exact fp32 MFMA chain) or "f16x3" (error-compensated f16 matrix cores)."""
+    precision: "f32" (exact fp32 MFMA chain) or "f16x3" (error-compensated f16 matrix cores; `range_flag`, an
+    int32[1] device tensor, receives POPE_RANGE_INPUT when an operand leaves the f16 range)."""
     a = _f32c(a, "linear")
     weight = _f32c(weight, "linear.w")
     n, k = weight.shape
@@ -39,11 +49,12 @@ def linear(a, weight, bias=None, epilogue=EPI_BIAS, gamma=None, res=None, out=No
         out = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32)
     with on_device_of(a):
         check(_lib.lib().pope_linear_prec_f32(ptr(a), ptr(weight), ptr(bias), ptr(out), m, n, k, epilogue, ptr(gamma),
-                                              ptr(res), _lib.PRECISIONS[precision], stream_of(a.device)), "pope_linear_prec_f32")
+                                              ptr(res), _lib.PRECISIONS[precision], _flag_ptr(range_flag), stream_of(a.device)),
+                  "pope_linear_prec_f32")
     return out
 
 
-def patch_embed(img, proj_w, posb, patch, precision="f32"):
+def patch_embed(img, proj_w, posb, patch, precision="f32", range_flag=None):
     """PatchEmbed + cls + pos (patch_embed.py:69-82, vision_transformer.py:191-200).  precision="f16x3": patches are
     gathered into hi/lo f16 planes and multiplied on the f16 matrix cores (3 MFMAs per product, fp32 accumulate)."""
     img = _f32c(img, "patch_embed")
@@ -62,7 +73,8 @@ def patch_embed(img, proj_w, posb, patch, precision="f32"):
         scratch = torch.empty(b * ntok * kp * 4, dtype=torch.uint8, device=img.device)
         with on_device_of(img):
             check(_lib.lib().pope_patch_embed_planes_f32(ptr(img), ptr(wp), ptr(_f32c(posb, "posb")), ptr(out), b, h, w, patch,
-                                                         dim, ptr(scratch), scratch.numel(), stream_of(img.device)),
+                                                         dim, ptr(scratch), scratch.numel(), _flag_ptr(range_flag),
+                                                         stream_of(img.device)),
                   "pope_patch_embed_planes_f32")
         return out
     with on_device_of(img):
@@ -71,7 +83,7 @@ def patch_embed(img, proj_w, posb, patch, precision="f32"):
     return out
 
 
-def attention(qkv, heads, precision="f32"):
+def attention(qkv, heads, precision="f32", range_flag=None):
     """softmax((q/8) k^T) v on qkv[B,N,3*heads*64] (attention.py:51-59)."""
     qkv = _f32c(qkv, "attention")
     b, n, d3 = qkv.shape
@@ -79,7 +91,7 @@ def attention(qkv, heads, precision="f32"):
     out = torch.empty(b, n, heads * 64, device=qkv.device, dtype=torch.float32)
     with on_device_of(qkv):
         check(_lib.lib().pope_attention_prec_f32(ptr(qkv), ptr(out), b, n, heads, _lib.PRECISIONS[precision],
-                                                 stream_of(qkv.device)), "pope_attention_prec_f32")
+                                                 _flag_ptr(range_flag), stream_of(qkv.device)), "pope_attention_prec_f32")
     return out
 
 

@@ -6,6 +6,9 @@ The reference runs this loop serially at batch 1 (eval_linemod_json.py:52-169); 
 independent, so here they are batched per GPU and sharded across GPUs with no data-path
 collective.
 """
+import json
+
+import numpy as np
 import torch
 
 from .matcher import dense_match
@@ -37,49 +40,120 @@ def gather_counts(local_counts, group=None):
     return torch.cat([o[:s] for o, s in zip(out, sizes)])
 
 
-class PairPipeline:
-    """extract(img0), extract(img1) -> dense_match, for a batch of pairs resident on one GPU."""
+def load_pair_list(path):
+    """Work list of an evaluation stream in the reference's walk order (eval_linemod_json.py:41-58: objects, then
+    rotation bins, then the bin's pairs).  File: {"objects": [{"dir": ..., "bins": {"0": [[idx0, idx1], ...], ...}}]}
+    (tests/golden/linemod_pairs.json holds the ids of the reference's data/pairs/LINEMOD-test.json).
+    Returns an int64 array [n_pairs, 4] of (object, bin, idx0, idx1) rows; the row number is the global pair id."""
+    with open(path) as f:
+        doc = json.load(f)
+    rows = []
+    for o, obj in enumerate(doc["objects"]):
+        for key, pairs in obj["bins"].items():
+            rows.extend((o, int(key), int(a), int(b)) for a, b in pairs)
+    return np.asarray(rows, dtype=np.int64).reshape(-1, 4)
 
-    def __init__(self, model, chunk=64, thr=0.2, border_rm=2, temperature=0.1, streams=1):
+
+def walk_pair_list(n_pairs, process_batch, batch=128, rank=0, world=1, group=None, device="cpu"):
+    """The per-pair loop of the reference's drivers (eval_linemod_json.py:41-169) for a list of independent pairs on
+    `world` GPUs: rank r owns the contiguous block shard_range(n_pairs, r, world) and walks it in batches of `batch`
+    pairs (the last batch of a shard is ragged); `process_batch(lo, hi)` returns the int32 match counts of global
+    pairs lo..hi-1; the single exchange is the gather of all counts at the end.  Returns (counts of ALL pairs in
+    list order [n_pairs] on `device`, number of batches this rank ran)."""
+    lo, hi = shard_range(n_pairs, rank, world)
+    parts, n_batches = [], 0
+    for s in range(lo, hi, batch):
+        e = min(s + batch, hi)
+        c = torch.as_tensor(process_batch(s, e), dtype=torch.int32)
+        if c.numel() != e - s:
+            raise ValueError(f"process_batch({s}, {e}) returned {c.numel()} counts")
+        parts.append(c.to(device))
+        n_batches += 1
+    local = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int32, device=device)
+    return gather_counts(local, group), n_batches
+
+
+class PairPipeline:
+    """extract(img0), extract(img1) -> dense_match, for a batch of pairs resident on one GPU.
+
+    f16x3 range guard (deferred form): every ViT chunk gets its own device flag word; the words are read at the
+    step's existing synchronisation point (the matcher's count readback) and a flagged chunk is re-run on the fp32
+    MFMA in place, followed by a new match — same process, no relaunch (`model.on_overflow` = "raise" raises)."""
+
+    def __init__(self, model, chunk=64, thr=0.2, border_rm=2, temperature=0.1, streams=1, want_conf=False,
+                 match_precision=None):
         self.model = model
         self.chunk = chunk
         self.thr, self.border_rm, self.temperature = thr, border_rm, temperature
         self.n_streams = streams
+        self.want_conf = want_conf  # publish conf_matrix [n, L, S] (the drop-in CoarseMatching always does)
+        self.match_precision = match_precision  # arithmetic of the L x S x C contraction (None: matcher default)
         self._streams = None
+        self.reruns = 0
+
+    def _chunk(self, images, tokens, s, flag=None, precision=None):
+        self.model(images[s:s + self.chunk], is_training=True, out_norm=tokens[s:s + self.chunk], range_flag=flag,
+                   precision=precision)
 
     @torch.no_grad()
-    def extract(self, images):
-        """[B,3,H,W] -> x_norm_patchtokens [B, H/14*W/14, dim], processed `chunk` images at a time.
+    def extract(self, images, flags=None):
+        """[B,3,H,W] -> final-norm tokens [B, 1 + H/14*W/14, dim] (row 0 = CLS), `chunk` images per launch sequence.
+        `flags`: int32 [ceil(B/chunk)] zeroed device tensor receiving the chunks' f16x3 range-guard words (None: each
+        chunk checks its own flag, one host synchronisation per chunk).
         With streams > 1 consecutive chunks run on different HIP streams (own scratch each), so the
         HBM-bound kernels and the tile-quantisation tails of one chunk overlap the MFMA phases of another."""
         starts = list(range(0, images.shape[0], self.chunk))
         B, _, H, W = images.shape
         p = self.model.patch_size
+        ntok = 1 + (H // p) * (W // p)
         # every chunk writes its normalised tokens straight into its slice of one buffer: no concatenation pass
-        tokens = torch.empty(B, 1 + (H // p) * (W // p), self.model.embed_dim, device=images.device, dtype=torch.float32)
+        tokens = torch.empty(B, ntok, self.model.embed_dim, device=images.device, dtype=torch.float32)
+        fl = (lambda k: None) if flags is None else (lambda k: flags[k:k + 1])
         if self.n_streams <= 1 or len(starts) == 1:
-            for s in starts:
-                self.model(images[s:s + self.chunk], is_training=True, out_norm=tokens[s:s + self.chunk])
-            return tokens[:, 1:]
+            for k, s in enumerate(starts):
+                self._chunk(images, tokens, s, fl(k))
+            return tokens
         main = torch.cuda.current_stream(images.device)
+        # the lazily built caches (weight planes, pos/bias table) are filled on the MAIN stream before the fork: side
+        # stream 1 must not read pointers whose contents side stream 0 is still writing
+        with torch.cuda.device(images.device):
+            self.model._weights()
+            self.model._posb(H, W, ntok)
         if self._streams is None:
             self._streams = [torch.cuda.Stream(images.device) for _ in range(self.n_streams)]
         for st in self._streams:
             st.wait_stream(main)
         for k, s in enumerate(starts):
             with torch.cuda.stream(self._streams[k % self.n_streams]):
-                self.model(images[s:s + self.chunk], is_training=True, out_norm=tokens[s:s + self.chunk])
+                self._chunk(images, tokens, s, fl(k))
         for st in self._streams:
             main.wait_stream(st)
-        return tokens[:, 1:]
+        return tokens
+
+    def _match(self, t0, t1, hw_c, hw_i):
+        return dense_match(t0[:, 1:], t1[:, 1:], hw_c, hw_c, hw_i, self.thr, self.border_rm, self.temperature,
+                           precision=self.match_precision, on_overflow=self.model.on_overflow, want_conf=self.want_conf)
 
     @torch.no_grad()
     def __call__(self, img0, img1):
         assert img0.shape == img1.shape
         n, _, H, W = img0.shape
         p = self.model.patch_size
-        f0, f1 = self.extract(img0), self.extract(img1)
+        n_chunks = -(-n // self.chunk)
+        flags = torch.zeros(2 * n_chunks, dtype=torch.int32, device=img0.device)
+        t0, t1 = self.extract(img0, flags[:n_chunks]), self.extract(img1, flags[n_chunks:])
         hw_c = (H // p, W // p)
-        out = dense_match(f0, f1, hw_c, hw_c, (H, W), self.thr, self.border_rm, self.temperature)
-        out["feat0"], out["feat1"] = f0, f1
+        out = self._match(t0, t1, hw_c, (H, W))   # synchronises (count readback)
+        bits = flags.cpu()
+        if int(bits.abs().sum()):
+            self.model.range_overflow(int(np.bitwise_or.reduce(bits.numpy())))   # raises under "raise"
+            for k in range(n_chunks):
+                if int(bits[k]):
+                    self._chunk(img0, t0, k * self.chunk, precision="f32")
+                if int(bits[n_chunks + k]):
+                    self._chunk(img1, t1, k * self.chunk, precision="f32")
+            self.reruns += 1
+            out = self._match(t0, t1, hw_c, (H, W))
+        out["feat0"], out["feat1"] = t0[:, 1:], t1[:, 1:]
+        out["cls0"], out["cls1"] = t0[:, 0], t1[:, 0]
         return out

@@ -77,6 +77,37 @@ def synthetic_pairs(n_pairs, h=476, w=630, seed=0, shift=(14, 28), noise=0.1, de
     return img0.to(device), img1.contiguous().to(device)
 
 
+def _hash_uniform(ids, n_per, salt, device):
+    """[len(ids), n_per] floats in [0, 1): a counter-based integer hash of (id, element index, salt).  Integer and
+    exact-float arithmetic only, so a pair's pixels depend on its id alone — not on the batch it rides in, the rank
+    that owns it or the device that evaluates the expression."""
+    i = torch.arange(n_per, device=device, dtype=torch.int64)[None, :]
+    x = (ids.to(device=device, dtype=torch.int64)[:, None] * 0x9E3779B1 + i * 0x85EBCA6B + salt * 0xC2B2AE35) & 0xFFFFFFFF
+    x = ((x ^ (x >> 16)) * 0x7FEB352D) & 0xFFFFFFFF
+    x = ((x ^ (x >> 15)) * 0x846CA68B) & 0xFFFFFFFF
+    x = x ^ (x >> 16)
+    return (x >> 8).to(torch.float32) / 16777216.0
+
+
+def pairs_by_id(ids, h=476, w=630, shift=(14, 28), noise=0.1, device="cpu"):
+    """Synthetic pixels for the pairs of a work list (BASELINE config 4: only the pair ids of the LINEMOD list
+    travel): frame = hash-uniform 640x480, centre crop (h, w), ImageNet normalisation; the second image
+    is the rolled first plus noise * (Irwin-Hall sum of four hash-uniforms, unit variance)."""
+    ids = torch.as_tensor(ids, dtype=torch.int64)
+    n, full_h, full_w = len(ids), max(480, h), max(640, w)
+    img = _hash_uniform(ids, 3 * full_h * full_w, 1, device).view(n, 3, full_h, full_w)
+    top, left = (full_h - h) // 2, (full_w - w) // 2
+    mean = torch.tensor(IMAGENET_MEAN, device=device).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=device).view(1, 3, 1, 1)
+    img0 = ((img[:, :, top:top + h, left:left + w] - mean) / std).contiguous()
+    del img
+    img1 = torch.roll(img0, shifts=shift, dims=(2, 3))
+    if noise > 0:
+        z = sum(_hash_uniform(ids, 3 * h * w, 2 + k, device) for k in range(4)).view(n, 3, h, w)
+        img1 = img1 + (noise * math.sqrt(3.0)) * (z - 2.0)
+    return img0, img1.contiguous()
+
+
 def synthetic_matcher_state_dict(seed=0, cfg=None):
     """Seeded synthetic LoFTR `Matcher` weights in the reference checkpoint layout (211 keys,
     src/matcher/matcher.py:18-27; weights/matcher.pth is not available offline).  Fan-in scaled normal

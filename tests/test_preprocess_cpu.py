@@ -35,3 +35,15 @@ def test_gray_and_tensor_inputs():
     assert torch.equal(a, b)
     un = a * torch.tensor(IMAGENET_STD).view(3, 1, 1) + torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
     assert torch.allclose(un[0], un[1], atol=1e-6) and float(un.min()) >= -1e-6 and float(un.max()) <= 1 + 1e-6
+
+
+def test_pairs_by_id_depend_on_the_id_only():
+    """Synthetic pixels of a work-list pair (BASELINE config 4) are a pure function of its id: the same pair gives the
+    same images whatever batch, shard or rank it is generated in."""
+    import torch
+    from pope_amd import synth
+    a0, a1 = synth.pairs_by_id([5, 9, 100], 56, 70)
+    b0, b1 = synth.pairs_by_id([9], 56, 70)
+    assert torch.equal(a0[1], b0[0]) and torch.equal(a1[1], b1[0]) and not torch.equal(a0[0], a0[1])
+    noise = a1 - torch.roll(a0, (14, 28), (2, 3))
+    assert abs(float(noise.std()) - 0.1) < 5e-3 and abs(float(noise.mean())) < 5e-3
