@@ -43,28 +43,7 @@ constexpr size_t X3_ATTN_EPI_BYTES = size_t(32) * 8 * OST * sizeof(float);  // O
 __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
-// residual v - float(hi): v_fma_mix_f32 reads the f16 half directly (one instruction instead of v_cvt_f32_f16 + v_sub)
-__device__ __forceinline__ float resid_lo(float v, unsigned hi_pair) {
-    float d;
-    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi_pair), "v"(v));
-    return d;
-}
-__device__ __forceinline__ float resid_hi(float v, unsigned hi_pair) {
-    float d;
-    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi_pair), "v"(v));
-    return d;
-}
-__device__ __forceinline__ void split4(f32x4 v, f16x4& hi, f16x4& lo) {
-    hi = __builtin_convertvector(v, f16x4);
-#ifdef ATTN_NO_FMA_MIX
-    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
-#else
-    typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
-    const u32x2s hp = __builtin_bit_cast(u32x2s, hi);
-    const f32x4 d = {resid_lo(v[0], hp[0]), resid_hi(v[1], hp[0]), resid_lo(v[2], hp[1]), resid_hi(v[3], hp[1])};
-    lo = __builtin_convertvector(d, f16x4);
-#endif
-}
+__device__ __forceinline__ void split4(f32x4 v, f16x4& hi, f16x4& lo) { pope_split4(v, hi, lo); }  // common.h
 __device__ __forceinline__ f16x8 cat(f16x4 a, f16x4 b) { return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
     float d;
@@ -489,8 +468,11 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
             for (int i = 8; i < 15; ++i) sm_mt = vmax3(sm_mt, c1[i], c0[i + 1]);
             sm_mt = vmax3(sm_mt, c1[15], c1[15]);
         } else if (slot == 2) {
-            sm_mt = __builtin_fmaxf(sm_mt, __shfl_xor(sm_mt, 32));
-            const float m_new = __builtin_fmaxf(m_run, sm_mt);
+            // the row maximum lives in lanes l and l ^ 32: v_permlane32_swap hands each half the other's value in one
+            // instruction (a __shfl_xor is a ds_bpermute: 7 address instructions, an LDS round trip and a wait)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, sm_mt),
+                                                             __builtin_bit_cast(unsigned, sm_mt), false, false);
+            const float m_new = vmax3(m_run, __builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
             sm_alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
             sm_shift = m_new - 10.0f;

@@ -79,6 +79,28 @@ static inline bool pope_opt_in_lds(K kernel, size_t bytes, pope_dev_mask& done) 
     return true;
 }
 
+// ---- f16x3 operand split ------------------------------------------------------------------------------------------
+// x = hi + lo with hi = f16(x) (RNE) and lo = f16(x - hi): x - hi is exact in fp32, so lo is its correctly rounded f16.
+// v_fma_mixlo/mixhi_f16 read the f16 half of `hi` directly and write the f16 result into one half of the destination:
+// four instructions produce the four lo halves of a quad (instead of 4 x v_cvt_f32_f16 + 4 x v_sub + 2 x v_cvt_pk) —
+// bit-identical results, 6 instead of 12 VALU instructions per quad.
+typedef _Float16 pope_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned pope_split_lo_pair(float v0, float v1, unsigned hi_pair) {
+    // two statements: the first result may share v0's register (v0 is dead after it) — the allocator decides; hi_pair
+    // stays live across both, so the half-written destination never aliases it
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi_pair), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hi_pair), "v"(v1));
+    return d;
+}
+__device__ __forceinline__ void pope_split4(f32x4 v, pope_f16x4& hi, pope_f16x4& lo) {
+    typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+    hi = __builtin_convertvector(v, pope_f16x4);  // 2 x v_cvt_pk_f16_f32 (RNE)
+    const u32x2s hp = __builtin_bit_cast(u32x2s, hi);
+    const u32x2s lp = {pope_split_lo_pair(v[0], v[1], hp[0]), pope_split_lo_pair(v[2], v[3], hp[1])};
+    lo = __builtin_bit_cast(pope_f16x4, lp);
+}
+
 // ---- f16x3 range guard ------------------------------------------------------------------------------------------
 // A planes producer converts value * scale to f16; a finite fp32 value whose scaled magnitude reaches 65520 rounds
 // to +-inf there (and poisons everything downstream) although the fp32 reference is fine.  Every producer therefore
@@ -91,6 +113,11 @@ __device__ __forceinline__ void pope_range_flag(unsigned* flag, unsigned bit, bo
 __device__ __forceinline__ float pope_amax4(float m, f32x4 v) {
     return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])),
                            __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])), m));
+}
+// two independent running maxima (m[0] over elements 0-1, m[1] over 2-3): no serial chain through one register
+__device__ __forceinline__ void pope_amax4x2(f32x2& m, f32x4 v) {
+    m[0] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), m[0]);
+    m[1] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])), m[1]);
 }
 __device__ __forceinline__ float pope_amax2(float m, f32x2 v) {
     return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), m);

@@ -47,9 +47,7 @@ static_assert(size_t(STAGE2) * sizeof(_Float16) >= size_t(4) * 32 * EPI_ST * siz
 constexpr float A_SCALE = 8.0f, W_SCALE = 256.0f;  // powers of two: exact
 
 __device__ __forceinline__ void split(f32x4 v, float scale, f16x4& hi, f16x4& lo) {
-    v = v * scale;
-    hi = __builtin_convertvector(v, f16x4);                          // v_cvt_pk_f16_f32 x2 (RNE)
-    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
+    pope_split4(v * scale, hi, lo);   // common.h: v_cvt_pk_f16_f32 x2 + v_fma_mixlo/mixhi_f16 x2
 }
 
 __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
@@ -415,7 +413,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
         }
         __syncthreads();  // all waves have finished reading the last K-step stage
         float* E = epi + wave * 32 * EPI_ST2;
-        float amax = 0.f;  // OUT_PLANES: largest magnitude written as planes (range guard)
+        f32x2 amax = {0.f, 0.f};  // OUT_PLANES: largest magnitude written as planes (range guard)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -453,7 +451,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
                     }
                     if constexpr (OUT_PLANES) {
                         f16x4 hi, lo;
-                        amax = pope_amax4(amax, v);
+                        pope_amax4x2(amax, v);
                         split(v, A_SCALE, hi, lo);
                         const unsigned o = col_ok[ni] ? off + unsigned((col[ni] >> 5) * 128 + (col[ni] & 31) * 2) : DROP;
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rc, o, 0, 2);
@@ -466,7 +464,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-        if constexpr (OUT_PLANES) pope_range_flag(g.range_flag, g.range_bit, !(amax * A_SCALE < POPE_F16_OVERFLOW));
+        if constexpr (OUT_PLANES) pope_range_flag(g.range_flag, g.range_bit, !(__builtin_fmaxf(amax[0], amax[1]) * A_SCALE < POPE_F16_OVERFLOW));
         __syncthreads();  // epilogue staging is drained before the stage is written again
     };
     auto epilogue = [&](int tile, float* epi) {
@@ -549,7 +547,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
         constexpr unsigned DROP = 0xFFFFFF00u;  // beyond every buffer extent: the access is discarded
         __syncthreads();  // all waves have finished reading the last K-step stage
         float* E = epi + wave * 32 * EPI_ST;
-        float amax = 0.f;  // OUT_PLANES: largest magnitude written as planes (range guard; rows >= M hold finite junk
+        f32x2 amax = {0.f, 0.f};  // OUT_PLANES: largest magnitude written as planes (range guard; rows >= M hold finite junk
                            // computed from zero-filled operands: bias / gelu(bias), the same values as real rows see)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -588,7 +586,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
                 }
                 if constexpr (OUT_PLANES) {
                     f16x4 hi, lo;
-                    amax = pope_amax4(amax, v);
+                    pope_amax4x2(amax, v);
                     split(v, A_SCALE, hi, lo);
                     // planes row: per 32-column chunk [32 hi | 32 lo] halves.  (Trading halves between neighbouring
                     // lanes so that each lane issues one 16-byte store — even lanes hi, odd lanes lo — was 6 % slower.)
@@ -610,7 +608,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (OUT_PLANES) pope_range_flag(g.range_flag, g.range_bit, !(amax * A_SCALE < POPE_F16_OVERFLOW));
+        if constexpr (OUT_PLANES) pope_range_flag(g.range_flag, g.range_bit, !(__builtin_fmaxf(amax[0], amax[1]) * A_SCALE < POPE_F16_OVERFLOW));
         __syncthreads();  // epilogue staging is drained before the stage is written again
     };
 

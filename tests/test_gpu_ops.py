@@ -216,16 +216,16 @@ def test_linear_planes_kernel(dev, hip_lib, epi):
     P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     if epi == "gelu_planes_out":
         op = torch.empty(M, N // 32, 2, 32, dtype=torch.float16, device=dev)
-        assert hip_lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), None, P(op), M, N, K, 1, None, None, st) == 0
+        assert hip_lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), None, P(op), M, N, K, 1, None, None, None, st) == 0
         got, want = _lib.from_planes(op.cpu(), _lib.PLANES_ACT_SCALE), F.gelu(lin).float()
     elif epi == "ls_res":
         gamma, res = 0.3 + 0.1 * _rand(N, seed=64), _rand(M, N, seed=65)
         x = res.to(dev).clone()
-        assert hip_lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(x), None, M, N, K, 2, P(gamma.to(dev)), P(x), st) == 0
+        assert hip_lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(x), None, M, N, K, 2, P(gamma.to(dev)), P(x), None, st) == 0
         got, want = x.cpu(), (res.double() + lin * gamma.double()).float()
     else:
         out = torch.empty(M, N, device=dev)
-        assert hip_lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(out), None, M, N, K, 0, None, None, st) == 0
+        assert hip_lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(out), None, M, N, K, 0, None, None, None, st) == 0
         got, want = out.cpu(), lin.float()
     _close(got, want, atol=1e-5, rtol=1e-5)
 
@@ -245,7 +245,7 @@ def test_linear_planes_ragged_shapes(dev, hip_lib, shape):
     P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     guard = torch.full((M + 2, N), 7.0, device=dev)      # rows M, M+1 must stay untouched
     for _ in range(2):
-        assert hip_lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(guard), None, M, N, K, 0, None, None, st) == 0
+        assert hip_lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(guard), None, M, N, K, 0, None, None, None, st) == 0
     assert bool((guard[M:] == 7.0).all())
     _close(guard[:M].cpu(), F.linear(a.double(), w.double(), b.double()).float(), atol=1e-5, rtol=1e-5)
 
@@ -267,13 +267,13 @@ P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 lin = F.linear(a.double(), w.double(), b.double())
 out = torch.empty(M, N, device=dev)
-assert lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(out), None, M, N, K, 0, None, None, st) == 0
+assert lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(out), None, M, N, K, 0, None, None, None, st) == 0
 e0 = float((out.cpu().double() - lin).abs().max())
 op = torch.empty(M, N // 32, 2, 32, dtype=torch.float16, device=dev)
-assert lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), None, P(op), M, N, K, 1, None, None, st) == 0
+assert lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), None, P(op), M, N, K, 1, None, None, None, st) == 0
 e1 = float((_lib.from_planes(op.cpu(), 8.0).double() - F.gelu(lin)).abs().max())
 gam = (0.3 + 0.1 * torch.randn(N, generator=g)); res = torch.randn(M, N, generator=g); x = res.to(dev).clone()
-assert lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(x), None, M, N, K, 2, P(gam.to(dev)), P(x), st) == 0
+assert lib.pope_linear_planes_f32(P(ap), P(wp), P(bd), P(x), None, M, N, K, 2, P(gam.to(dev)), P(x), None, st) == 0
 e2 = float((x.cpu().double() - (res.double() + lin * gam.double())).abs().max())
 print("ERR", e0, e1, e2)
 assert max(e0, e1, e2) < 2e-5
@@ -295,10 +295,10 @@ def test_layernorm_planes_and_split(dev, hip_lib):
     yp = torch.empty(rows, dim // 32, 2, 32, dtype=torch.float16, device=dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: C.c_void_p(t.data_ptr())
-    assert hip_lib.pope_layernorm_planes_f32(P(x.to(dev)), P(w.to(dev)), P(b.to(dev)), P(yp), rows, dim, 1e-6, st) == 0
+    assert hip_lib.pope_layernorm_planes_f32(P(x.to(dev)), P(w.to(dev)), P(b.to(dev)), P(yp), rows, dim, 1e-6, None, st) == 0
     _close(_lib.from_planes(yp.cpu(), _lib.PLANES_ACT_SCALE), want, atol=3e-6)
     # the device splitter == the torch formulation used for the weight planes (bit for bit)
     src = _rand(1000, 64, seed=74, scale=0.05)
     sp = torch.empty(1000, 2, 2, 32, dtype=torch.float16, device=dev)
-    assert hip_lib.pope_split_planes_f32(P(src.to(dev)), P(sp), 1000, 64, _lib.PLANES_W_SCALE, st) == 0
+    assert hip_lib.pope_split_planes_f32(P(src.to(dev)), P(sp), 1000, 64, _lib.PLANES_W_SCALE, None, st) == 0
     assert torch.equal(sp.cpu(), _lib.to_planes(src, _lib.PLANES_W_SCALE))
