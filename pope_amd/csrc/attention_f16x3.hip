@@ -466,13 +466,15 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         } else if (slot == 1) {
 #pragma unroll
             for (int i = 8; i < 15; ++i) sm_mt = vmax3(sm_mt, c1[i], c0[i + 1]);
-            sm_mt = vmax3(sm_mt, c1[15], c1[15]);
+            sm_mt = __builtin_fmaxf(sm_mt, c1[15]);   // compiler-generated: feeds the permlane swap of slot 2
         } else if (slot == 2) {
             // the row maximum lives in lanes l and l ^ 32: v_permlane32_swap hands each half the other's value in one
-            // instruction (a __shfl_xor is a ds_bpermute: 7 address instructions, an LDS round trip and a wait)
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, sm_mt),
-                                                             __builtin_bit_cast(unsigned, sm_mt), false, false);
-            const float m_new = vmax3(m_run, __builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+            // instruction (a __shfl_xor is a ds_bpermute: 7 address instructions, an LDS round trip and a wait).  Its
+            // operand and its results are touched by COMPILER-generated instructions only: the hazard recognizer does
+            // not look into inline asm, and VALU write -> permlane swap -> VALU read need wait states on gfx950.
+            float ma, mb;
+            pope_xor32_pair(sm_mt, ma, mb);
+            const float m_new = __builtin_fmaxf(m_run, __builtin_fmaxf(ma, mb));
             sm_alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
             sm_shift = m_new - 10.0f;

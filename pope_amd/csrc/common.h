@@ -34,6 +34,24 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Cross-lane exchange over lane distance 16 / 32 in ONE instruction (gfx950 v_permlane16/32_swap_b32): both results
+// together hold, in every lane l, the values of lanes l and l ^ 16 (l ^ 32) — in a fixed order per lane, so a
+// commutative combine (max, a + b) is deterministic.  (__shfl_xor is a ds_bpermute: address arithmetic + LDS trip.)
+__device__ __forceinline__ void pope_xor16_pair(float v, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    // (elements are copied to scalars first: __builtin_bit_cast applied to r[1] directly reads element 0 with this clang)
+    const unsigned r0 = r[0], r1 = r[1];
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void pope_xor32_pair(float v, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    // (elements are copied to scalars first: __builtin_bit_cast applied to r[1] directly reads element 0 with this clang)
+    const unsigned r0 = r[0], r1 = r[1];
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+
 // Blocks b and b+8 share an XCD (round-robin dispatch).  Remap so that each XCD walks a
 // contiguous chunk of the logical tile space (neighbouring tiles share operand panels in
 // that XCD's private L2).  Bijective for any grid size; affects speed only.

@@ -473,16 +473,74 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
             return;
         }
         if constexpr (EPI == EPI_SIM) {
-            // similarity tile of batch b: (acc * alpha) / divisor -> C[b][row][col]; rows >= M and columns >= N belong
-            // to the next batch's operands (or the zero fill) and are dropped; N even: 8-byte stores
+            // Similarity tile of batch b: sim = acc / divisor_eff (divisor_eff = T * 2^16: the operand scales are exact
+            // powers of two), stored to C[b][row][col], plus this wave's partial softmax statistics of the tile — the
+            // dual softmax of coarse_matching.py:119 needs max and sum(exp) of every row AND every column of sim, and
+            // computing their per-tile pieces here, from registers, replaces two full passes over the L x S matrix.
+            // Rows >= M and columns >= N belong to the next batch's operands (or the zero fill): they are set to -inf
+            // right after the scaling, so they vanish from every maximum and every sum; their stores are dropped.
             const int b = tile / tiles_pb, rem = tile - b * tiles_pb;
-            const int m0s = (rem / tiles_n) * BMT, n0s = (rem % tiles_n) * BN;
+            const int tm = rem / tiles_n, tn = rem - tm * tiles_n;
+            const int m0s = tm * BMT, n0s = tn * BN;
             const int cols = n0s + wn * 64 + ec4;
             constexpr unsigned DROPS = 0xFFFFFF00u;
+            constexpr float L2E = 1.44269504088896340736f;
+            // x / d with a reciprocal and one correction step (q = x r; e = x - d q (exact fma); q += e r): the correctly
+            // rounded quotient for all but pathological divisors, 3 instructions instead of the ~10 of a full division
+            const float dv = g.divisor_eff, rdiv = g.rdiv;
+            const bool edge = m0s + BMT > g.M || n0s + BN > g.N;   // wave-uniform
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float x = acc[mi][ni][i];
+                        float q = x * rdiv;
+                        q = __builtin_fmaf(__builtin_fmaf(-dv, q, x), rdiv, q);
+                        acc[mi][ni][i] = q;
+                    }
+            if (edge) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const bool row_out = m0s + wm * 64 + mi * 32 + r >= g.M;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (row_out || n0s + wn * 64 + ni * 32 + mfma32_row(i, h) >= g.N) acc[mi][ni][i] = -INFINITY;
+                }
+            }
             __syncthreads();
             float* Es = epi + wave * 32 * EPI_ST;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
+                // ---- row statistics over this wave's 64 columns, in the accumulator layout: lane (r, h) holds 32 of
+                // row r's 64 values, lane (r, h ^ 1) the others
+                if (g.row_part) {
+                    float m = acc[mi][0][0];
+#pragma unroll
+                    for (int i = 1; i < 16; ++i) m = __builtin_fmaxf(m, acc[mi][0][i]);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) m = __builtin_fmaxf(m, acc[mi][1][i]);
+                    float ma, mb;
+                    pope_xor32_pair(m, ma, mb);
+                    m = __builtin_fmaxf(ma, mb);
+                    const float ms = m == -INFINITY ? 0.f : m;   // an all-padding block contributes (max -inf, sum 0)
+                    f32x2 sum = {0.f, 0.f};
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int i = 0; i < 16; i += 2)
+                            sum += f32x2{__builtin_amdgcn_exp2f((acc[mi][ni][i] - ms) * L2E),
+                                         __builtin_amdgcn_exp2f((acc[mi][ni][i + 1] - ms) * L2E)};
+                    float sa, sb;
+                    pope_xor32_pair(sum[0] + sum[1], sa, sb);
+                    const int row = m0s + wm * 64 + mi * 32 + r;
+                    if (h == 0 && row < g.M)
+                        *reinterpret_cast<f32x2*>(g.row_part + ((size_t(b) * g.M + row) * g.ncb + tn * 2 + wn) * 2) = f32x2{m, sa + sb};
+                }
+                // ---- transposition to rows, coalesced store of sim, column statistics over this block's 32 rows
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -493,12 +551,14 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
                         *reinterpret_cast<f32x4*>(&Es[r * EPI_ST + ni * 32 + 8 * g4 + 4 * h]) = v;
                     }
                 __builtin_amdgcn_wave_barrier();
+                f32x4 vr[8];
+                f32x4 cm = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(&Es[(elr + 4 * i) * EPI_ST + ec4]);
+                    const f32x4 v = vr[i] = *reinterpret_cast<const f32x4*>(&Es[(elr + 4 * i) * EPI_ST + ec4]);
                     const int row = m0s + wm * 64 + mi * 32 + elr + 4 * i;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (v[e] * g.alpha) / g.divisor;
+                    for (int e = 0; e < 4; ++e) cm[e] = __builtin_fmaxf(cm[e], v[e]);
                     const unsigned off = (unsigned(b) * unsigned(g.M) + unsigned(row)) * c_row_bytes + unsigned(cols) * 4u;
                     const bool row_ok = row < g.M;
                     if (!(g.N & 1)) {
@@ -511,6 +571,35 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (row_ok && cols + e < g.N) __builtin_nontemporal_store(v[e], cp + e);
+                    }
+                }
+                if (g.col_pmax) {
+                    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {   // the four lane groups (lane >> 4) hold 8 rows each
+                        float a, c;
+                        pope_xor16_pair(cm[e], a, c);
+                        pope_xor32_pair(__builtin_fmaxf(a, c), a, c);
+                        cm[e] = __builtin_fmaxf(a, c);
+                    }
+                    f32x4 cms;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cms[e] = cm[e] == -INFINITY ? 0.f : cm[e];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) cs[e] += __builtin_amdgcn_exp2f((vr[i][e] - cms[e]) * L2E);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a, c;
+                        pope_xor16_pair(cs[e], a, c);
+                        pope_xor32_pair(a + c, a, c);
+                        cs[e] = a + c;
+                    }
+                    if (elr == 0 && cols < g.N) {   // ldp is a multiple of 4 and cols too: the quad never leaves the row
+                        const size_t o = (size_t(b) * g.nrb + tm * 4 + wm * 2 + mi) * g.ldp + cols;
+                        *reinterpret_cast<f32x4*>(g.col_pmax + o) = cm;
+                        *reinterpret_cast<f32x4*>(g.col_psum + o) = cs;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -769,7 +858,11 @@ int launch_planes(const GemmParams& g, hipStream_t stream) {
 // Batched similarity for the dense matcher: C[b] = (A[b] . W[b]^T * alpha) / divisor on planes operands.
 int pope_launch_sim_f16x3_planes(const GemmParams& g, hipStream_t stream) {
     if (g.epilogue != EPI_SIM || !g.a_pl || !g.w_pl || !g.C || g.nbatch <= 0 || g.M <= 0 || g.N <= 0) return POPE_ERR_ARG;
-    if (g.K < 2 * BK || (g.K % BK) || (g.lda & 31) || (g.ldw & 31) || g.ldc != g.N || g.divisor == 0.f) return POPE_ERR_ARG;
+    if (g.K < 2 * BK || (g.K % BK) || (g.lda & 31) || (g.ldw & 31) || g.ldc != g.N || g.divisor_eff == 0.f) return POPE_ERR_ARG;
+    if ((g.row_part || g.col_pmax) &&
+        (!g.row_part || !g.col_pmax || !g.col_psum || g.ncb != 2 * ((g.N + BN - 1) / BN) || g.nrb != 4 * ((g.M + BM - 1) / BM) ||
+         g.ldp < g.N || (g.ldp & 3)))
+        return POPE_ERR_ARG;
     if ((size_t(g.nbatch) * g.M + BM) * g.lda * 4 >= (size_t(1) << 32) || (size_t(g.nbatch) * g.N + BN) * g.ldw * 4 >= (size_t(1) << 32) ||
         (size_t(g.nbatch) * g.M + BM) * g.ldc * 4 >= (size_t(1) << 32) - 512)
         return POPE_ERR_ARG;

@@ -27,6 +27,16 @@ struct GemmParams {
     // C [nbatch, rows_a, rows_w] fp32 (ldc = rows_w); M = rows_a, N = rows_w
     int nbatch;
     float alpha, divisor;
+    // EPI_SIM fused softmax statistics (dense matcher, match.hip): every wave writes, for its 64-column block, the
+    // (max, sum exp(. - max)) of each of its rows, and for each of its two 32-row blocks the same per column:
+    //   row_part  [nbatch][M][ncb]      float2, ncb = 2 * ceil(N / 128)
+    //   col_pmax / col_psum [nbatch][nrb][ldp] floats, nrb = 4 * ceil(M / 128), ldp = N rounded up to 4
+    // divisor_eff = divisor / alpha and rdiv = 1 / divisor_eff (host, correctly rounded): sim = acc / divisor_eff
+    float* row_part;
+    float* col_pmax;
+    float* col_psum;
+    int ncb, nrb, ldp;
+    float divisor_eff, rdiv;
     int res_mod;         // > 0: the residual row is (row % res_mod) of a [res_mod, ldres] table (patch embed: pos + bias)
     // f16x3 "planes" operands (gemm_f16x3.hip, planes kernel): a tensor X[rows, ld] kept as two f16
     // planes with X = (hi + lo) / scale (power-of-two scale: activations 8, weights 256).  The planes
