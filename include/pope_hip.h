@@ -183,26 +183,20 @@ int pope_event_elapsed_ms(void* start, void* stop, float* ms_host);  /* both eve
 
 /* ---- dense matcher --------------------------------------------------------------------------- */
 
-size_t pope_dense_match_workspace_bytes(int n, int L, int S);
-
 /* CoarseMatching.forward + get_coarse_match (eval, dual-softmax) —
  * src/matcher/utils/coarse_matching.py:106-119,151-261.
  * feat0[n,L,C], feat1[n,S,C] with `stride0`/`stride1` elements between consecutive pairs (L*C / S*C
  * when dense; larger when the features are the patch rows of an x_norm[B,1+L,C] buffer);
  * grids (h0,w0),(h1,w1); scale = hw0_i[0]/hw0_c[0].
- * conf_matrix[n,L,S]: published confidence matrix (required; it doubles as the sim buffer).
+ * conf_matrix[n,L,S]: the published confidence matrix (the drop-in CoarseMatching publishes it,
+ * coarse_matching.py:145), or NULL for callers that only consume the match lists: the matrix then lives in the
+ * workspace as sim only and is never written a second time.
  * Outputs have capacity n*L: b_ids,i_ids,j_ids (int64), mconf, mkpts0_c/mkpts1_c [.,2] (x,y);
- * counts[n+1] (int32): matches per pair, then the total M (read it after synchronising). */
-int pope_dense_match_f32(const float* feat0, long long stride0, const float* feat1, long long stride1,
-                         int n, int L, int S, int C,
-                         int h0, int w0, int h1, int w1, float thr, int border_rm, float temperature,
-                         float scale, float* conf_matrix, long long* b_ids, long long* i_ids,
-                         long long* j_ids, float* mconf, float* mkpts0_c, float* mkpts1_c, int* counts,
-                         void* workspace, size_t workspace_bytes, void* stream);
-/* Same with an explicit POPE_PREC_* for the L x S x C contraction (pope_dense_match_f32 == POPE_PREC_F32_MFMA).
- * POPE_PREC_F16X3 needs C % 32 == 0 and the larger workspace of pope_dense_match_workspace_bytes_prec (the two
- * feature tensors as hi/lo planes of feat / sqrt(C)); everything after the contraction is identical. */
-size_t pope_dense_match_workspace_bytes_prec(int n, int L, int S, int C, int precision);
+ * counts[n+1] (int32): matches per pair, then the total M (read it after synchronising).
+ * precision = POPE_PREC_* of the L x S x C contraction; POPE_PREC_F16X3 needs C % 32 == 0 (feat / sqrt(C) kept as
+ * hi/lo planes, range-guarded: POPE_RANGE_MATCH); everything after the contraction is identical.
+ * Workspace: pope_dense_match_workspace_bytes_prec(n, L, S, C, precision, conf_matrix != NULL). */
+size_t pope_dense_match_workspace_bytes_prec(int n, int L, int S, int C, int precision, int publish_conf);
 int pope_dense_match_prec_f32(const float* feat0, long long stride0, const float* feat1, long long stride1,
                               int n, int L, int S, int C, int h0, int w0, int h1, int w1,
                               float thr, int border_rm, float temperature, float scale,
@@ -210,6 +204,14 @@ int pope_dense_match_prec_f32(const float* feat0, long long stride0, const float
                               float* mconf, float* mkpts0_c, float* mkpts1_c, int* counts,
                               void* workspace, size_t workspace_bytes, int precision, unsigned* range_flag,
                               void* stream);
+/* Shorthands: POPE_PREC_F32_MFMA, conf_matrix published, no range flag. */
+size_t pope_dense_match_workspace_bytes(int n, int L, int S);
+int pope_dense_match_f32(const float* feat0, long long stride0, const float* feat1, long long stride1,
+                         int n, int L, int S, int C,
+                         int h0, int w0, int h1, int w1, float thr, int border_rm, float temperature,
+                         float scale, float* conf_matrix, long long* b_ids, long long* i_ids,
+                         long long* j_ids, float* mconf, float* mkpts0_c, float* mkpts1_c, int* counts,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- host-side helper ------------------------------------------------------------------------ */
 

@@ -70,7 +70,7 @@ PROTOTYPES = {
     "pope_dense_match_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_float,
                                                                                   C.c_float] + [C.c_void_p] * 8
                              + [C.c_void_p, C.c_size_t, C.c_void_p]),
-    "pope_dense_match_workspace_bytes_prec": (C.c_size_t, [C.c_int] * 5),
+    "pope_dense_match_workspace_bytes_prec": (C.c_size_t, [C.c_int] * 6),
     "pope_dense_match_prec_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 8
                                   + [C.c_float, C.c_int, C.c_float, C.c_float] + [C.c_void_p] * 8
                                   + [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),

@@ -364,17 +364,38 @@ int pope_event_elapsed_ms(void* start, void* stop, float* ms_host) {
                ? POPE_OK : POPE_ERR_LAUNCH;
 }
 
+namespace {
+// workspace carving of the dense matcher, shared by the size query and the launcher
+struct MatchLayout {
+    size_t nl, ns, part, rowp, colp, pl0, pl1, simb, total;
+    int ncb, nrb, nrb2, ldp;
+    MatchLayout(int n, int L, int S, int C, int precision, bool publish_conf) {
+        nl = align_up(size_t(n) * L * 4, 256);
+        ns = align_up(size_t(n) * S * 4, 256);
+        ncb = 2 * ((S + 127) / 128);
+        nrb = 4 * ((L + 127) / 128);
+        nrb2 = pope_match_nrb2(L);
+        ldp = (S + 3) & ~3;
+        part = align_up(size_t(n) * nrb2 * ldp * 4, 256);
+        const bool x3 = precision == POPE_PREC_F16X3;
+        rowp = x3 ? align_up(size_t(n) * L * ncb * 8, 256) : 0;
+        colp = x3 ? align_up(size_t(n) * nrb * ldp * 4, 256) : 0;
+        pl0 = x3 ? align_up(size_t(n) * L * C * 4, 256) : 0;
+        pl1 = x3 ? align_up(size_t(n) * S * C * 4, 256) : 0;
+        simb = publish_conf ? 0 : align_up(size_t(n) * L * S * 4, 256);
+        total = 7 * nl + 3 * ns + part + rowp + 2 * colp + pl0 + pl1 + simb;
+    }
+};
+}  // namespace
+
 size_t pope_dense_match_workspace_bytes(int n, int L, int S) {
     if (n <= 0 || L <= 0 || S <= 0) return 0;
-    const size_t nl = align_up(size_t(n) * L * 4, 256), ns = align_up(size_t(n) * S * 4, 256);
-    return 5 * nl + 3 * ns;  // row_max,row_sum,conf_rowmax,row_j,row_conf | col_max,col_sum,conf_colmax
+    return MatchLayout(n, L, S, 4, POPE_PREC_F32_MFMA, true).total;
 }
 
-size_t pope_dense_match_workspace_bytes_prec(int n, int L, int S, int C, int precision) {
-    const size_t base = pope_dense_match_workspace_bytes(n, L, S);
-    if (!base || C <= 0) return 0;
-    if (precision != POPE_PREC_F16X3) return base;
-    return base + align_up(size_t(n) * L * C * 4, 256) + align_up(size_t(n) * S * C * 4, 256);
+size_t pope_dense_match_workspace_bytes_prec(int n, int L, int S, int C, int precision, int publish_conf) {
+    if (n <= 0 || L <= 0 || S <= 0 || C <= 0) return 0;
+    return MatchLayout(n, L, S, C, precision, publish_conf != 0).total;
 }
 
 int pope_dense_match_f32(const float* feat0, long long stride0, const float* feat1, long long stride1, int n, int L,
@@ -392,32 +413,42 @@ int pope_dense_match_prec_f32(const float* feat0, long long stride0, const float
                               float* mkpts1_c, int* counts, void* workspace, size_t workspace_bytes, int precision,
                               unsigned* range_flag, void* stream) {
     StreamDevice on_device(stream);
-    if (!feat0 || !feat1 || !conf_matrix || !b_ids || !i_ids || !j_ids || !mconf || !mkpts0_c || !mkpts1_c ||
-        !counts || !workspace)
+    if (!feat0 || !feat1 || !b_ids || !i_ids || !j_ids || !mconf || !mkpts0_c || !mkpts1_c || !counts || !workspace)
         return POPE_ERR_ARG;
+    if (n <= 0 || L <= 0 || S <= 0 || C <= 0) return POPE_ERR_ARG;
     if (precision != POPE_PREC_F32_MFMA && precision != POPE_PREC_F16X3) return POPE_ERR_ARG;
-    if (workspace_bytes < pope_dense_match_workspace_bytes_prec(n, L, S, C, precision)) return POPE_ERR_WORKSPACE;
-    const size_t nl = align_up(size_t(n) * L * 4, 256), ns = align_up(size_t(n) * S * 4, 256);
+    const bool publish = conf_matrix != nullptr;
+    const MatchLayout lay(n, L, S, C, precision, publish);
+    if (workspace_bytes < lay.total) return POPE_ERR_WORKSPACE;
     char* ws = static_cast<char*>(workspace);
+    auto take = [&](size_t bytes) { char* q = ws; ws += bytes; return q; };
     MatchParams p = {};
     p.feat0 = feat0; p.feat1 = feat1;
     p.n = n; p.L = L; p.S = S; p.C = C;
     p.bs0 = stride0; p.bs1 = stride1;
     p.h0 = h0; p.w0 = w0; p.h1 = h1; p.w1 = w1;
     p.thr = thr; p.temperature = temperature; p.border = border_rm; p.scale = scale;
-    p.sim = conf_matrix;
-    p.row_max = reinterpret_cast<float*>(ws);
-    p.row_sum = reinterpret_cast<float*>(ws + nl);
-    p.conf_rowmax = reinterpret_cast<float*>(ws + 2 * nl);
-    p.row_j = reinterpret_cast<int*>(ws + 3 * nl);
-    p.row_conf = reinterpret_cast<float*>(ws + 4 * nl);
-    p.col_max = reinterpret_cast<float*>(ws + 5 * nl);
-    p.col_sum = reinterpret_cast<float*>(ws + 5 * nl + ns);
-    p.conf_colmax = reinterpret_cast<unsigned*>(ws + 5 * nl + 2 * ns);
+    p.publish_conf = publish;
+    p.ncb = lay.ncb; p.nrb = lay.nrb; p.nrb2 = lay.nrb2; p.ldp = lay.ldp;
+    p.row_max = reinterpret_cast<float*>(take(lay.nl));
+    p.row_sum = reinterpret_cast<float*>(take(lay.nl));
+    p.conf_rowmax = reinterpret_cast<float*>(take(lay.nl));
+    p.row_j = reinterpret_cast<int*>(take(lay.nl));
+    p.row_conf = reinterpret_cast<float*>(take(lay.nl));
+    p.row_arg = reinterpret_cast<int*>(take(lay.nl));
+    p.row_cnt = reinterpret_cast<int*>(take(lay.nl));
+    p.col_max = reinterpret_cast<float*>(take(lay.ns));
+    p.col_sum = reinterpret_cast<float*>(take(lay.ns));
+    p.conf_colmax = reinterpret_cast<float*>(take(lay.ns));
+    p.colmax_part = reinterpret_cast<float*>(take(lay.part));
     if (precision == POPE_PREC_F16X3) {
-        p.planes0 = ws + 5 * nl + 3 * ns;
-        p.planes1 = ws + 5 * nl + 3 * ns + align_up(size_t(n) * L * C * 4, 256);
+        p.row_part = reinterpret_cast<float*>(take(lay.rowp));
+        p.col_pmax = reinterpret_cast<float*>(take(lay.colp));
+        p.col_psum = reinterpret_cast<float*>(take(lay.colp));
+        p.planes0 = take(lay.pl0);
+        p.planes1 = take(lay.pl1);
     }
+    p.sim = publish ? conf_matrix : reinterpret_cast<float*>(take(lay.simb));
     p.counts = counts;
     p.range_flag = range_flag;
     p.b_ids = b_ids; p.i_ids = i_ids; p.j_ids = j_ids;

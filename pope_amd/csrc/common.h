@@ -52,6 +52,15 @@ __device__ __forceinline__ void pope_xor32_pair(float v, float& a, float& b) {
     b = __builtin_bit_cast(float, r1);
 }
 
+// Wave-uniform select that can never become control flow: the compiler turns chains of scalar ?: into branches at will,
+// and a branch inside a software-pipelined K-step splits its basic block (the instruction-mix pins then no longer
+// reach across it).  c != 0 ? a : b, all three in SGPRs.
+__device__ __forceinline__ int pope_uniform_select(int c, int a, int b) {
+    int r;
+    asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(r) : "s"(c), "s"(a), "s"(b) : "scc");
+    return r;
+}
+
 // Blocks b and b+8 share an XCD (round-robin dispatch).  Remap so that each XCD walks a
 // contiguous chunk of the logical tile space (neighbouring tiles share operand panels in
 // that XCD's private L2).  Bijective for any grid size; affects speed only.

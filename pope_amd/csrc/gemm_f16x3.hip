@@ -272,10 +272,14 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
     // solo rate), instead of filling both workgroup slots of the first XCDs' CUs while the other XCDs idle.
     const int grid = gridDim.x, full_rounds = n_tiles / grid;
     const int remapped = xcd_remap(blockIdx.x, grid);
+    // The stream bookkeeping must not become control flow: a K-step has to stay ONE basic block for the pinned
+    // instruction mix below (with compiler-chosen branches here, the LDS writes and loads of an item form a block of
+    // their own in front of the MFMAs and the matrix pipe idles under them) -> asm selects on scalars.
+    const int tail_cand = full_rounds * grid + int(blockIdx.x);
+    const int tail_tile = tail_cand < n_tiles ? tail_cand : n_tiles;
     auto tile_of = [&](int ord) -> int {
-        if (ord < full_rounds) return ord * grid + remapped;
-        const int t = full_rounds * grid + int(blockIdx.x);
-        return (ord == full_rounds && t < n_tiles) ? t : n_tiles;
+        const int in_tail = pope_uniform_select(ord == full_rounds, tail_tile, n_tiles);
+        return pope_uniform_select(ord < full_rounds, ord * grid + remapped, in_tail);
     };
     const int first = tile_of(0);
     if (first >= n_tiles) return;
@@ -312,7 +316,10 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
 #endif
                 st[NA + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, ld_kt * 128, 0);
             }
-            if (++ld_kt == nk) { ld_kt = 0; ld_tile = tile_of(++ld_ord); }
+            const int wrap = ++ld_kt == nk;
+            ld_kt = pope_uniform_select(wrap, 0, ld_kt);
+            ld_ord += wrap;
+            ld_tile = tile_of(ld_ord);
         }
     };
     auto write_stage = [&](int s, const u32x4 (&st)[NLD]) {

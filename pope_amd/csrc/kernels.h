@@ -104,12 +104,19 @@ struct MatchParams {
     float thr, temperature;
     int border;
     float scale;         // hw0_i[0] / hw0_c[0]
-    float* sim;          // [n, L, S] workspace (sim, then conf in place)
+    float* sim;          // [n, L, S]: sim; conf in place when publish_conf (then it is the caller's conf_matrix)
+    int publish_conf;
     void* planes0; void* planes1;  // optional scratch [n*L*C] / [n*S*C] floats-worth: similarity on the f16 matrix cores
-    float* row_max; float* row_sum;  // [n, L]
-    float* col_max; float* col_sum;  // [n, S]
-    unsigned* conf_colmax;           // [n, S] (float bits, conf > 0)
+    // pieces of the softmax statistics written by the f16x3 contraction's epilogue (GemmParams: row_part, col_pmax, col_psum)
+    float* row_part; float* col_pmax; float* col_psum;
+    int ncb, nrb, ldp;               // 2 * ceil(S/128), 4 * ceil(L/128), S rounded up to 4
+    float* row_max; float* row_sum;  // [n, L]   softmax(sim, dim=2) statistics
+    float* col_max; float* col_sum;  // [n, S]   softmax(sim, dim=1) statistics
+    float* colmax_part;              // [n, nrb2, ldp] column maxima of conf per 32-row block
+    int nrb2;                        // pope_match_nrb2(L)
+    float* conf_colmax;              // [n, S]
     float* conf_rowmax;              // [n, L]
+    int* row_arg; int* row_cnt;      // [n, L]  first argmax column of conf, number of columns attaining the maximum
     int* row_j;                      // [n, L]  matched column or -1
     float* row_conf;                 // [n, L]
     unsigned* range_flag;            // optional f16x3 range-guard word (POPE_RANGE_MATCH)
@@ -118,4 +125,5 @@ struct MatchParams {
     long long* b_ids; long long* i_ids; long long* j_ids;
     float* mconf; float* mkpts0; float* mkpts1;
 };
+int pope_match_nrb2(int L);
 int pope_launch_dense_match_f32(const MatchParams& p, hipStream_t stream);

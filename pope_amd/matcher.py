@@ -67,9 +67,9 @@ def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, tempera
     if Cc % 32 or Cc < 64:
         precision = "f32"   # the planes layout needs whole 32-column chunks
     prec = _lib.PRECISIONS[precision]
-    ws_bytes = lib.pope_dense_match_workspace_bytes_prec(n, L, S, Cc, prec)
+    ws_bytes = lib.pope_dense_match_workspace_bytes_prec(n, L, S, Cc, prec, 1 if want_conf else 0)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    conf = torch.empty(n, L, S, dtype=torch.float32, device=dev)
+    conf = torch.empty(n, L, S, dtype=torch.float32, device=dev) if want_conf else None
     cap = n * L
     b_ids = torch.empty(cap, dtype=torch.int64, device=dev)
     i_ids = torch.empty(cap, dtype=torch.int64, device=dev)
@@ -98,7 +98,7 @@ def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, tempera
     m = int(counts_h[n])
     b_ids, i_ids, j_ids, mconf = b_ids[:m], i_ids[:m], j_ids[:m], mconf[:m]
     return {
-        "conf_matrix": conf if want_conf else None,
+        "conf_matrix": conf,
         "b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids,
         "gt_mask": mconf == 0, "m_bids": b_ids,          # eval: mconf > thr, the `!= 0` filter is a no-op
         "mkpts0_c": mk0[:m], "mkpts1_c": mk1[:m], "mconf": mconf,
