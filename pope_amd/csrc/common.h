@@ -56,8 +56,11 @@ __device__ __forceinline__ void pope_xor32_pair(float v, float& a, float& b) {
 // and a branch inside a software-pipelined K-step splits its basic block (the instruction-mix pins then no longer
 // reach across it).  c != 0 ? a : b, all three in SGPRs.
 __device__ __forceinline__ int pope_uniform_select(int c, int a, int b) {
-    int r;
-    asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(r) : "s"(c), "s"(a), "s"(b) : "scc");
+    int r;   // readfirstlane: the operands are wave-uniform by contract; this pins them to SGPRs for the "s" constraints
+    asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, %3"
+        : "=s"(r)
+        : "s"(__builtin_amdgcn_readfirstlane(c)), "s"(__builtin_amdgcn_readfirstlane(a)), "s"(__builtin_amdgcn_readfirstlane(b))
+        : "scc");
     return r;
 }
 

@@ -496,6 +496,12 @@ __global__ __launch_bounds__(BMT * 2, 2) void gemm_nt_f16x3_planes_kernel(const 
             // rounded quotient for all but pathological divisors, 3 instructions instead of the ~10 of a full division
             const float dv = g.divisor_eff, rdiv = g.rdiv;
             const bool edge = m0s + BMT > g.M || n0s + BN > g.N;   // wave-uniform
+            // pin the epilogue arithmetic behind the tile-end branch (the compiler otherwise speculates the scaling
+            // and the edge selects into every K-step: 300 VALU instructions per 24 MFMAs)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
