@@ -235,6 +235,39 @@ def gen_pair_lists():
     print("linemod_pairs.json:", n, "pairs")
 
 
+def gen_vit_archs():
+    """BASELINE config 5, DINOv2 half: the ViT-B/14 and ViT-L/14 backbones of the reference
+    (dinov2/dinov2/models/vision_transformer.py:319-342: 768-d / 12 heads / 12 blocks and 1024-d / 16 heads / 24 blocks,
+    same eval config as load_dinov2_model) on one 224 x 224 image, seeded synthetic weights with the gamma = O(1)
+    recipe; strided rows keep the fixtures small."""
+    from dinov2.dinov2.models import vision_transformer as vits
+    for name, ctor, dim, depth in (("vitb_224", vits.vit_base, 768, 12), ("vitl_224", vits.vit_large, 1024, 24)):
+        sd = synth.synthetic_state_dict(seed=0, dim=dim, depth=depth)
+        model = ctor(patch_size=14, img_size=518, init_values=1e-5, ffn_layer="mlp", block_chunks=0, qkv_bias=True,
+                     proj_bias=True, ffn_bias=True)
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        x = synth.synthetic_images(1, 224, 224, seed=11)
+        tap_blocks = (0, depth // 2, depth - 1)
+        out, taps = run_ref_vit(model, x, tap_blocks)
+        o_taps = {}
+        mine = dinov2_ref.forward_features(sd, x, taps=o_taps)
+        d = {k: maxdiff(out[k], mine[k]) for k in ("x_norm_clstoken", "x_norm_patchtokens", "x_prenorm")}
+        for i in tap_blocks:
+            d[f"blk{i}"] = maxdiff(taps[f"blk{i}"], o_taps[i]["x_out"])
+        print(name, "oracle-vs-reference max abs diff:", {k: f"{v:.2e}" for k, v in d.items()})
+        assert max(d.values()) <= 2e-5, d
+        xn = torch.cat([out["x_norm_clstoken"][:, None], out["x_norm_patchtokens"]], 1)
+        rows = torch.arange(0, xn.shape[1], 8)
+        fx = {"weights_seed": 0, "arch": np.array([dim, depth, dim // 64]), "weights_digest": sd_digest(sd), "input_seed": 11,
+              "shape": np.array([1, 224, 224]), "rows": rows.numpy(), "tap_blocks": np.array(tap_blocks),
+              "input_digest": np.array([float(x.double().sum()), float(x.double().abs().sum())]),
+              "x_norm": xn[:, rows].numpy(), "x_prenorm": out["x_prenorm"][:, rows].numpy(), "cls": model(x).detach().numpy()}
+        for i in tap_blocks:
+            fx[f"blk{i}"] = taps[f"blk{i}"][:, rows].numpy()
+        np.savez(os.path.join(OUT, name + ".npz"), **fx)
+
+
 def sd_digest(sd):
     return np.array([float(sd[k].double().sum()) for k in sorted(sd)], np.float64)
 
@@ -243,10 +276,10 @@ def maxdiff(a, b):
     return float((a - b).abs().max())
 
 
-def run_ref_vit(model, x):
+def run_ref_vit(model, x, tap_blocks=(0, 5, 11)):
     taps = {}
     hooks = []
-    for i in (0, 5, 11):
+    for i in tap_blocks:
         blk = model.blocks[i]
         hooks.append(blk.attn.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(f"attn{i}", o.detach())))
         hooks.append(blk.mlp.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(f"mlp{i}", o.detach())))
@@ -264,6 +297,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-pairs" in sys.argv:
         return gen_pair_lists()
+    if "--only-archs" in sys.argv:
+        return gen_vit_archs()
     if "--only-loftr" in sys.argv:
         return gen_loftr()
     if "--only-driver" in sys.argv:
@@ -378,6 +413,7 @@ def main():
     gen_loftr()
     gen_driver()
     gen_pair_lists()
+    gen_vit_archs()
     print("golden fixtures written to", OUT)
 
 

@@ -379,11 +379,127 @@ __global__ __launch_bounds__(256) void scatter_kernel(const MatchParams p) {
     }
 }
 
+// Fast form for even S (rows 8-byte aligned): no control flow inside a row.  A lane owns the column pairs
+// c0 + 128 k + 2 l (k < NK); a row's NK 8-byte pieces are fetched by bounds-checked buffer loads (columns past S read
+// 0 and give conf 0, their stores are dropped), all in flight together and one row ahead of the arithmetic; conf, the
+// running column maxima and the row maximum cost two max + one compare per element; the first argmax and the tie
+// count come from wave ballots on the scalar unit.  NK = ceil(S / 128) for S <= 2048 (DINOv2 tokens at 476 x 630: 12;
+// LoFTR 256^2: 8); wider matrices are walked in chunks of 2048 columns, lane 0 merging a row's chunk results.
+template <bool PUBLISH, int NK>
+__global__ __launch_bounds__(256) void conf_pass_fast_kernel(const MatchParams p) {
+    __shared__ float cmax_s[4][128 * NK];
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2m;
+    constexpr int RPW = CP_ROWS / 4;   // rows per wave
+    constexpr int BIG = 1 << 24;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.y, blk = blockIdx.x;
+    const int row0 = blk * CP_ROWS + wave * RPW;
+    const size_t prow = size_t(pair) * p.L;
+    const float* cmx_g = p.col_max + size_t(pair) * p.S;
+    const float* csum_g = p.col_sum + size_t(pair) * p.S;
+    const int last_row = p.L - 1;
+
+    for (int c0 = 0; c0 < p.S; c0 += 128 * NK) {
+        f32x2 cmx[NK], cinv[NK], cbest[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int col = c0 + 128 * k + 2 * lane + e;
+                const bool ok = col < p.S;
+                cmx[k][e] = ok ? cmx_g[col] : 0.f;
+                cinv[k][e] = ok ? 1.0f / csum_g[col] : 0.f;
+                cbest[k][e] = 0.f;
+            }
+        const unsigned voff = unsigned(c0 + 2 * lane) * 4u;
+        auto row_rsrc = [&](int row) {   // rows past the end re-read the last row (never used)
+            const int rr = row < last_row ? row : last_row;
+            return __builtin_amdgcn_make_buffer_rsrc(p.sim + (prow + rr) * p.S, 0, unsigned(p.S) * 4u, 0x00020000);
+        };
+        auto fetch = [&](int row, f32x2 (&c)[NK]) {
+            const __amdgpu_buffer_rsrc_t rs = row_rsrc(row);
+#pragma unroll
+            for (int k = 0; k < NK; ++k) c[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 512 * k, 0));
+        };
+        auto process = [&](int row, f32x2 (&c)[NK]) {
+            if (row > last_row) return;   // wave-uniform, tail block only
+            const float rmx = p.row_max[prow + row], rinv = 1.0f / p.row_sum[prow + row];
+            float m = 0.f;   // conf >= 0
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                c[k] = f32x2{conf_value(c[k][0], cmx[k][0], cinv[k][0], rmx, rinv), conf_value(c[k][1], cmx[k][1], cinv[k][1], rmx, rinv)};
+                cbest[k][0] = fmaxf(cbest[k][0], c[k][0]);
+                cbest[k][1] = fmaxf(cbest[k][1], c[k][1]);
+                m = fmaxf(m, fmaxf(c[k][0], c[k][1]));
+            }
+            if constexpr (PUBLISH) {
+                const __amdgpu_buffer_rsrc_t rs = row_rsrc(row);
+#pragma unroll
+                for (int k = 0; k < NK; ++k) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2m, c[k]), rs, voff, 512 * k, 0);
+            }
+            m = wave_max(m);
+            // first argmax and tie count within this chunk, on the scalar unit (columns ascend with k, then lane, then e;
+            // asm selects: the compiler must not turn this into 2 NK branches)
+            int first = BIG, cnt = 0;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const unsigned long long m0 = __ballot(c[k][0] == m), m1 = __ballot(c[k][1] == m);
+                cnt += __popcll(m0) + __popcll(m1);
+                const int a = pope_uniform_select(m0 != 0, 2 * __builtin_ctzll(m0 | (1ull << 63)), BIG);
+                const int b2 = pope_uniform_select(m1 != 0, 2 * __builtin_ctzll(m1 | (1ull << 63)) + 1, BIG);
+                const int cand = c0 + 128 * k + (a < b2 ? a : b2);
+                first = first < cand ? first : cand;   // BIG + offsets stay far above any column
+            }
+            if (lane == 0) {
+                float bv = m;
+                int bi = first, bc = cnt;
+                if (c0) {   // merge with the earlier chunks of this row (same lane wrote them)
+                    const float pv = p.conf_rowmax[prow + row];
+                    const int pi = p.row_arg[prow + row], pc = p.row_cnt[prow + row];
+                    if (pv > m) { bv = pv; bi = pi; bc = pc; }
+                    else if (pv == m) { bi = pi; bc = pc + cnt; }
+                }
+                p.conf_rowmax[prow + row] = bv;
+                p.row_arg[prow + row] = bi;
+                p.row_cnt[prow + row] = bc;
+            }
+        };
+        f32x2 ca[NK], cb[NK];
+        fetch(row0, ca);
+#pragma unroll 1
+        for (int r = 0; r < RPW; r += 2) {
+            fetch(row0 + r + 1, cb);
+            process(row0 + r, ca);
+            fetch(row0 + r + 2, ca);
+            process(row0 + r + 1, cb);
+        }
+        if (c0) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NK; ++k) *reinterpret_cast<f32x2*>(&cmax_s[wave][128 * k + 2 * lane]) = cbest[k];
+        __syncthreads();
+        float* out = p.colmax_part + (size_t(pair) * p.nrb2 + blk) * p.ldp;
+        for (int cc = threadIdx.x; cc < 128 * NK && c0 + cc < p.S; cc += 256)
+            out[c0 + cc] = fmaxf(fmaxf(cmax_s[0][cc], cmax_s[1][cc]), fmaxf(cmax_s[2][cc], cmax_s[3][cc]));
+    }
+}
+
+template <bool PUBLISH>
+void launch_conf_pass(const MatchParams& p, hipStream_t stream) {
+    const dim3 blocks((p.L + CP_ROWS - 1) / CP_ROWS, p.n);
+    if (p.S & 1) {   // odd S: rows are only 4-byte aligned
+        hipLaunchKernelGGL((conf_pass_kernel<PUBLISH, false>), blocks, dim3(256), 0, stream, p);
+        return;
+    }
+    const int nk = (p.S + 127) / 128;
+    if (nk <= 4) hipLaunchKernelGGL((conf_pass_fast_kernel<PUBLISH, 4>), blocks, dim3(256), 0, stream, p);
+    else if (nk <= 8) hipLaunchKernelGGL((conf_pass_fast_kernel<PUBLISH, 8>), blocks, dim3(256), 0, stream, p);
+    else if (nk <= 12) hipLaunchKernelGGL((conf_pass_fast_kernel<PUBLISH, 12>), blocks, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conf_pass_fast_kernel<PUBLISH, 16>), blocks, dim3(256), 0, stream, p);
+}
+
 template <bool PUBLISH>
 void launch_conf_and_select(const MatchParams& p, hipStream_t stream) {
-    const dim3 blocks((p.L + CP_ROWS - 1) / CP_ROWS, p.n);
-    if (p.S & 1) hipLaunchKernelGGL((conf_pass_kernel<PUBLISH, false>), blocks, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conf_pass_kernel<PUBLISH, true>), blocks, dim3(256), 0, stream, p);
+    launch_conf_pass<PUBLISH>(p, stream);
     hipLaunchKernelGGL(combine_colmax_kernel, dim3((p.S + 255) / 256, p.n), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(select_kernel<PUBLISH>, dim3((p.L + 3) / 4, p.n), dim3(256), 0, stream, p);
 }

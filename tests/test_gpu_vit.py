@@ -125,3 +125,40 @@ def test_vote_top3_matches_reference_loop(model, sd0):
     np.testing.assert_allclose(scores.cpu().numpy(), want_scores.numpy(), rtol=0, atol=1e-5)
     _, want_idx = cm.streaming_top3(want_scores.numpy())
     assert list(idx) == list(want_idx) and 4 in idx
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+@pytest.mark.parametrize("name", ["vitb_224", "vitl_224"])
+def test_vit_base_and_large_match_reference_fixture(hip_lib, golden_dir, name, prec):
+    """BASELINE config 5, DINOv2 half: the ViT-B/14 (768-d, 12 heads) and ViT-L/14 (1024-d, 16 heads, 24 blocks)
+    backbones of the reference (vision_transformer.py:319-342) through the same kernels — fixtures generated by the
+    reference's own vit_base / vit_large (oracle/gen_golden.py:gen_vit_archs)."""
+    from pope_amd import dinov2, synth
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    dim, depth, heads = (int(v) for v in fx["arch"])
+    ctor = dinov2.vit_base if dim == 768 else dinov2.vit_large
+    m = ctor(patch_size=14, img_size=518, init_values=1e-5, ffn_layer="mlp", block_chunks=0)
+    assert m.embed_dim == dim and m.n_blocks == depth and m.num_heads == heads
+    m.load_state_dict(synth.synthetic_state_dict(seed=int(fx["weights_seed"]), dim=dim, depth=depth), strict=True)
+    m = m.eval().to("cuda:0")
+    m.precision = prec
+    B, H, W = (int(v) for v in fx["shape"])
+    x = synth.synthetic_images(B, H, W, seed=int(fx["input_seed"]))
+    assert float(x.double().sum()) == fx["input_digest"][0]
+    out = m(x.cuda(), is_training=True)
+    rows = torch.from_numpy(fx["rows"])
+    xn = torch.cat([out["x_norm_clstoken"][:, None], out["x_norm_patchtokens"]], 1).cpu()[:, rows]
+    err = float(np.abs(xn.numpy() - fx["x_norm"]).max())
+    print(f"{name} [{prec}]: max |x_norm - reference| = {err:.2e}")
+    np.testing.assert_allclose(xn.numpy(), fx["x_norm"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(out["x_prenorm"].cpu()[:, rows].numpy(), fx["x_prenorm"], rtol=0, atol=5 * ATOL)
+    np.testing.assert_allclose(m(x.cuda()).cpu().numpy(), fx["cls"], rtol=0, atol=ATOL)
+    taps = [int(t) for t in fx["tap_blocks"]]
+    inter = m.get_intermediate_layers(x.cuda(), n=taps, norm=False, return_class_token=True)
+    for (patch, cls), i in zip(inter, taps):
+        blk = torch.cat([cls[:, None], patch], 1).cpu()[:, rows]
+        np.testing.assert_allclose(blk.numpy(), fx[f"blk{i}"], rtol=0, atol=5 * ATOL)
+    assert m.overflow_events == 0
+    # batch invariance at the wider shapes (16 heads / hidden 4096 grids)
+    x3 = torch.cat([synth.synthetic_images(2, H, W, seed=3), x]).cuda()
+    assert torch.equal(m(x3, is_training=True)["x_norm_patchtokens"][2], out["x_norm_patchtokens"][0])
