@@ -3,6 +3,7 @@
 #include "../../include/pope_hip.h"
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -263,21 +264,49 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
 
 #define POPE_MARK(kind) do { if (!rec.mark(kind, stream)) return POPE_ERR_ARG; } while (0)
 #define POPE_TRY(call) do { if ((rc = (call))) return rc; } while (0)
-    POPE_MARK(POPE_K_PATCH_EMBED);
     int rc;
-    if (planes && w->patch_wp)  // `big` is free here: it holds the im2col planes
+    void* xn_pl = xn;    // planes alias the xn / fc1 buffers: 2 x f16 per element = the fp32 footprint
+    void* hid_pl = hid;
+    // Fused form (dim 384): every residual GEMM (patch embed, proj, fc2) also emits the LayerNorm that follows it —
+    // as planes for the next GEMM, or as fp32 x_norm after the last block — so no stand-alone LayerNorm launch is left
+    // (gemm_rowln.hip).  POPE_NO_ROWLN=1: dev switch for A/B runs against the unfused sequence.
+    static const bool no_rowln = getenv("POPE_NO_ROWLN") && atoi(getenv("POPE_NO_ROWLN"));
+    GemmParams probe = {};
+    probe.M = rows; probe.N = dim; probe.K = dim; probe.lda = dim; probe.ldw = dim; probe.ldc = dim; probe.ldres = dim;
+    const bool fused = planes && w->patch_wp && !no_rowln && pope_gemm_rowln_supported(probe);
+    // residual GEMM + following LayerNorm: x = res + gamma * (a . W^T + bias); LN(x; ln_w, ln_b) -> planes or fp32
+    auto rowln = [&](const void* a_pl, const void* w_pl, int K, const float* bias, const float* gamma, const float* res, int res_mod,
+                     const float* ln_w, const float* ln_b, void* ln_planes, float* ln_f32) {
+        GemmParams g = {};
+        g.a_pl = a_pl; g.w_pl = w_pl; g.bias = bias; g.gamma = gamma; g.res = res; g.res_mod = res_mod;
+        g.C = x; g.M = rows; g.N = dim; g.K = K; g.lda = K; g.ldw = K; g.ldc = dim; g.ldres = dim;
+        g.epilogue = EPI_BIAS_LS_RES;
+        g.ln_w = ln_w; g.ln_b = ln_b; g.ln_eps = eps; g.ln_planes = ln_planes; g.ln_f32 = ln_f32;
+        g.range_flag = range_flag;
+        return pope_launch_gemm_rowln(g, stream);
+    };
+    POPE_MARK(POPE_K_PATCH_EMBED);
+    if (fused) {   // `big` is free here: it holds the im2col planes
+        const int kp = (3 * w->patch * w->patch + 31) & ~31;
+        if (workspace_bytes - size_t(reinterpret_cast<char*>(big) - ws) < size_t(rows) * kp * 4) return POPE_ERR_WORKSPACE;
+        POPE_TRY(pope_launch_im2col_planes(img, big, B, H, W, w->patch, kp, range_flag, stream));
+        const pope_vit_block_weights& k0 = w->blocks_host[0];
+        POPE_TRY(rowln(big, w->patch_wp, kp, nullptr, nullptr, posb, ntok, k0.norm1_w, k0.norm1_b, xn_pl, nullptr));
+    } else if (planes && w->patch_wp) {
         POPE_TRY(pope_patch_embed_planes_f32(img, w->patch_wp, posb, x, B, H, W, w->patch, dim, big,
                                              workspace_bytes - size_t(reinterpret_cast<char*>(big) - ws), range_flag, stream));
-    else
+    } else {
         POPE_TRY(pope_patch_embed_f32(img, w->patch_w, posb, x, B, H, W, w->patch, dim, stream));
+    }
     for (int i = 0; i < w->depth; ++i) {
         const pope_vit_block_weights& k = w->blocks_host[i];
-        void* xn_pl = xn;    // planes alias the xn / fc1 buffers: 2 x f16 per element = the fp32 footprint
-        void* hid_pl = hid;
+        const bool last = i + 1 == w->depth;
         // x = x + ls1(attn(norm1(x)))                                      block.py:105
-        POPE_MARK(POPE_K_LAYERNORM);
-        if (planes) POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm1_w, k.norm1_b, xn_pl, rows, dim, eps, range_flag, stream));
-        else POPE_TRY(pope_launch_layernorm_f32(x, dim, k.norm1_w, k.norm1_b, xn, dim, rows, dim, eps, stream));
+        if (!fused) {
+            POPE_MARK(POPE_K_LAYERNORM);
+            if (planes) POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm1_w, k.norm1_b, xn_pl, rows, dim, eps, range_flag, stream));
+            else POPE_TRY(pope_launch_layernorm_f32(x, dim, k.norm1_w, k.norm1_b, xn, dim, rows, dim, eps, stream));
+        }
         POPE_MARK(POPE_K_GEMM_QKV);
         if (planes)  // q, k, v stay planes from the QKV epilogue to the attention kernel's LDS
             POPE_TRY(pope_linear_planes_f32(xn_pl, k.qkv_wp, k.qkv_b, nullptr, qkv, rows, 3 * dim, dim, EPI_BIAS, nullptr, nullptr,
@@ -287,23 +316,34 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
         if (planes) POPE_TRY(pope_launch_attention_f16x3_planes_io(qkv, att, B, ntok, w->heads, stream));
         else POPE_TRY(pope_attention_prec_f32(qkv, att, B, ntok, w->heads, f32, nullptr, stream));
         POPE_MARK(POPE_K_GEMM_PROJ);
-        if (planes)
+        if (fused)
+            POPE_TRY(rowln(att, k.proj_wp, dim, k.proj_b, k.ls1, x, 0, k.norm2_w, k.norm2_b, xn_pl, nullptr));
+        else if (planes)
             POPE_TRY(pope_linear_planes_f32(att, k.proj_wp, k.proj_b, x, nullptr, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, nullptr, stream));
         else POPE_TRY(pope_linear_prec_f32(att, k.proj_w, k.proj_b, x, rows, dim, dim, EPI_BIAS_LS_RES, k.ls1, x, f32, nullptr, stream));
         // x = x + ls2(mlp(norm2(x)))                                       block.py:106
-        POPE_MARK(POPE_K_LAYERNORM);
-        if (planes) POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm2_w, k.norm2_b, xn_pl, rows, dim, eps, range_flag, stream));
-        else POPE_TRY(pope_launch_layernorm_f32(x, dim, k.norm2_w, k.norm2_b, xn, dim, rows, dim, eps, stream));
+        if (!fused) {
+            POPE_MARK(POPE_K_LAYERNORM);
+            if (planes) POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm2_w, k.norm2_b, xn_pl, rows, dim, eps, range_flag, stream));
+            else POPE_TRY(pope_launch_layernorm_f32(x, dim, k.norm2_w, k.norm2_b, xn, dim, rows, dim, eps, stream));
+        }
         POPE_MARK(POPE_K_GEMM_FC1);
         if (planes)
             POPE_TRY(pope_linear_planes_f32(xn_pl, k.fc1_wp, k.fc1_b, nullptr, hid_pl, rows, hidden, dim, EPI_BIAS_GELU, nullptr,
                                             nullptr, range_flag, stream));
         else POPE_TRY(pope_linear_prec_f32(xn, k.fc1_w, k.fc1_b, hid, rows, hidden, dim, EPI_BIAS_GELU, nullptr, nullptr, f32, nullptr, stream));
         POPE_MARK(POPE_K_GEMM_FC2);
-        if (planes)
+        if (fused && !last) {
+            const pope_vit_block_weights& kn = w->blocks_host[i + 1];
+            POPE_TRY(rowln(hid_pl, k.fc2_wp, hidden, k.fc2_b, k.ls2, x, 0, kn.norm1_w, kn.norm1_b, xn_pl, nullptr));
+        } else if (fused && x_norm) {   // last block: the final norm (vision_transformer.py:230) as fp32
+            POPE_TRY(rowln(hid_pl, k.fc2_wp, hidden, k.fc2_b, k.ls2, x, 0, w->norm_w, w->norm_b, nullptr, x_norm));
+        } else if (planes) {
             POPE_TRY(pope_linear_planes_f32(hid_pl, k.fc2_wp, k.fc2_b, x, nullptr, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x,
                                             nullptr, stream));
-        else POPE_TRY(pope_linear_prec_f32(hid, k.fc2_w, k.fc2_b, x, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x, f32, nullptr, stream));
+        } else {
+            POPE_TRY(pope_linear_prec_f32(hid, k.fc2_w, k.fc2_b, x, rows, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x, f32, nullptr, stream));
+        }
         for (int t = 0; t < n_taps; ++t)
             if (tap_blocks_host[t] == i && tap_out_host[t]) {
                 POPE_MARK(POPE_K_TAP_COPY);
@@ -312,7 +352,7 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
                     return POPE_ERR_LAUNCH;
             }
     }
-    if (x_norm) {
+    if (x_norm && !fused) {
         POPE_MARK(POPE_K_LAYERNORM);
         POPE_TRY(pope_launch_layernorm_f32(x, dim, w->norm_w, w->norm_b, x_norm, dim, rows, dim, eps, stream));
     }

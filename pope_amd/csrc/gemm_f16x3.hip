@@ -858,8 +858,16 @@ int launch_planes_t(const GemmParams& g, hipStream_t stream, int nbatch = 1) {
     return pope_check_launch();
 }
 
+// dev switch for same-box A/B runs: POPE_GEMM_MFMA=32 selects this file's v_mfma_f32_32x32x16_f16 mainloop instead of the
+// 16x16x32 kernel of gemm_planes.hip (the default: +13 % executed FLOP/s at the clock the chip holds, see that file)
+static bool use_mfma32() {
+    static const bool v = getenv("POPE_GEMM_MFMA") && atoi(getenv("POPE_GEMM_MFMA")) == 32;
+    return v;
+}
+
 template <int EPI, bool OUT_PLANES>
 int launch_planes(const GemmParams& g, hipStream_t stream) {
+    if (!use_mfma32()) return pope_launch_planes16(g, stream);
     static const int force = getenv("POPE_GEMM_BM") ? atoi(getenv("POPE_GEMM_BM")) : 0;  // dev switch: 128 or 256
     // Measured (DESIGN.md §4 finding 6): the 256-row kernel moves 25 % fewer LDS store bytes per MFMA and is 2-5 %
     // faster on QKV / FC1 in isolation, but inside the model (planes outputs, neighbours' cache state) the 128-row
@@ -880,6 +888,7 @@ int pope_launch_sim_f16x3_planes(const GemmParams& g, hipStream_t stream) {
         (size_t(g.nbatch) * g.M + BM) * g.ldc * 4 >= (size_t(1) << 32) - 512)
         return POPE_ERR_ARG;
     if (static_cast<long long>(g.nbatch) * ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) > 0x7fffffffLL) return POPE_ERR_ARG;
+    if (!use_mfma32()) return pope_launch_planes16(g, stream);
     return launch_planes_t<EPI_SIM, false, 128>(g, stream, g.nbatch);
 }
 

@@ -51,6 +51,12 @@ struct GemmParams {
     // not fit f16 after scaling; the on-the-fly f16x3 kernel checks its operands before the split
     unsigned* range_flag;
     unsigned range_bit;
+    // fused following LayerNorm (gemm_rowln.hip, N = 384): x = res + gamma * (A.W^T + bias) -> C, and
+    // LayerNorm(x) * ln_w + ln_b -> ln_planes (activation planes) or ln_f32 (exactly one of the two)
+    const float* ln_w; const float* ln_b;
+    float ln_eps;
+    void* ln_planes;
+    float* ln_f32;
     // patch-embed gather (EPI_POSB)
     const float* posb;   // [ntok, N]: row 0 = cls_token + pos[0]; row n = conv bias + pos[n]
     int ntok, img_h, img_w, patch, grid_w;
@@ -63,6 +69,11 @@ bool pope_gemm_f16x3_supported(const GemmParams& g);
 // Planes variant: W (and optionally A / C) as pre-split f16 planes, no splitting in the K loop.
 int pope_launch_gemm_nt_f16x3_planes(const GemmParams& g, hipStream_t stream);
 int pope_launch_sim_f16x3_planes(const GemmParams& g, hipStream_t stream);  // EPI_SIM, batched
+// residual GEMM + the following LayerNorm in one kernel (gemm_rowln.hip; N = 384 only: `supported` says)
+bool pope_gemm_rowln_supported(const GemmParams& g);
+int pope_launch_gemm_rowln(const GemmParams& g, hipStream_t stream);
+// the v_mfma_f32_16x16x32_f16 mainloop (gemm_planes.hip) behind both of the above; arguments already validated
+int pope_launch_planes16(const GemmParams& g, hipStream_t stream);
 constexpr float K_PLANES_ACT_SCALE = 8.0f, K_PLANES_W_SCALE = 256.0f;  // == POPE_PLANES_*_SCALE of pope_hip.h
 
 // y = LayerNorm(x) written as f16 planes (scale POPE_PLANES_ACT_SCALE), [rows, dim] halves each.
