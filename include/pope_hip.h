@@ -213,6 +213,25 @@ int pope_dense_match_f32(const float* feat0, long long stride0, const float* fea
                          long long* j_ids, float* mconf, float* mkpts0_c, float* mkpts1_c, int* counts,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- caller-side preprocessing, batched ------------------------------------------------- */
+
+/* set_torch_image for P crops at once — segment_anything/segment_anything/dinov2_utils.py:55-78: Resize (Pillow's
+ * 8-bit bilinear resample, bit-identical) -> CenterCrop -> ToTensor -> Normalize.  img_hwc[P,Hin,Win,3] uint8 (channel
+ * order as given: the drivers pass BGR); the window / weight tables of the two resample passes are DEVICE int32 arrays
+ * built by the host exactly as Pillow builds them (pope_amd/preprocess.py:resize_tables): hstart/hcount[OW],
+ * hk[OW,kh], vstart/vcount[OH], vk[OH,kv] with 22 fractional bits; (top,left,ch,cw) = crop window in the resized
+ * image; [row0, row0+nrows) = input rows those output rows read; mean_host/std_host[3] = HOST floats;
+ * out[P,3,ch,cw] fp32; scratch >= P*nrows*cw*3 bytes. */
+int pope_preprocess_u8_f32(const unsigned char* img_hwc, int P, int Hin, int Win,
+                           const int* hstart, const int* hcount, const int* hk, int kh,
+                           const int* vstart, const int* vcount, const int* vk, int kv,
+                           int top, int left, int ch, int cw, int row0, int nrows,
+                           const float* mean_host, const float* std_host, float* out,
+                           unsigned char* scratch, size_t scratch_bytes, void* stream);
+/* cv2.cvtColor(BGR2GRAY) (8-bit fixed point) followed by / 255. — eval_linemod_json.py:103-111:
+ * bgr_hwc[P,H,W,3] uint8 -> out[P,1,H,W] fp32 in [0,1] (the Matcher's input). */
+int pope_gray_u8_f32(const unsigned char* bgr_hwc, int P, int H, int W, float* out, void* stream);
+
 /* ---- host-side helper ------------------------------------------------------------------------ */
 
 /* Streaming top-3 proposal vote — eval_linemod_json.py:71,95-101 (HOST pointers): slots start at

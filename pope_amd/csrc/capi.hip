@@ -496,6 +496,29 @@ int pope_dense_match_prec_f32(const float* feat0, long long stride0, const float
     return pope_launch_dense_match_f32(p, static_cast<hipStream_t>(stream));
 }
 
+int pope_preprocess_u8_f32(const unsigned char* img_hwc, int P, int Hin, int Win, const int* hstart, const int* hcount,
+                           const int* hk, int kh, const int* vstart, const int* vcount, const int* vk, int kv, int top, int left,
+                           int ch, int cw, int row0, int nrows, const float* mean_host, const float* std_host, float* out,
+                           unsigned char* scratch, size_t scratch_bytes, void* stream) {
+    StreamDevice on_device(stream);
+    if (!mean_host || !std_host || P <= 0 || nrows <= 0 || cw <= 0) return POPE_ERR_ARG;
+    if (scratch_bytes < size_t(P) * nrows * cw * 3) return POPE_ERR_WORKSPACE;
+    PreprocParams p = {};
+    p.img = img_hwc; p.P = P; p.Hin = Hin; p.Win = Win;
+    p.hstart = hstart; p.hcount = hcount; p.hk = hk; p.kh = kh;
+    p.vstart = vstart; p.vcount = vcount; p.vk = vk; p.kv = kv;
+    p.top = top; p.left = left; p.ch = ch; p.cw = cw; p.row0 = row0; p.nrows = nrows;
+    for (int c = 0; c < 3; ++c) { p.mean[c] = mean_host[c]; p.std[c] = std_host[c]; }
+    p.tmp = scratch; p.out = out;
+    return pope_launch_preprocess(p, static_cast<hipStream_t>(stream));
+}
+
+int pope_gray_u8_f32(const unsigned char* bgr_hwc, int P, int H, int W, float* out, void* stream) {
+    StreamDevice on_device(stream);
+    if (P <= 0 || H <= 0 || W <= 0) return POPE_ERR_ARG;
+    return pope_launch_gray(bgr_hwc, size_t(P) * H * W, out, static_cast<hipStream_t>(stream));
+}
+
 int pope_streaming_top3_host(const float* scores, int P, float* slot_scores, long long* slot_index) {
     if (!scores || !slot_scores || !slot_index || P < 0) return POPE_ERR_ARG;
     for (int k = 0; k < 3; ++k) { slot_scores[k] = 0.f; slot_index[k] = -1; }

@@ -138,3 +138,19 @@ struct MatchParams {
 };
 int pope_match_nrb2(int L);
 int pope_launch_dense_match_f32(const MatchParams& p, hipStream_t stream);
+
+// Batched PIL-exact preprocessing (preprocess.hip): resize (window / fixed-point weight tables from the host) ->
+// centre crop -> /255 -> normalise, uint8 HWC [P, Hin, Win, 3] -> fp32 NCHW [P, 3, ch, cw]
+struct PreprocParams {
+    const unsigned char* img;
+    int P, Hin, Win;
+    const int *hstart, *hcount, *hk; int kh;   // horizontal tables, indexed by OUTPUT column of the full resized image
+    const int *vstart, *vcount, *vk; int kv;   // vertical tables, indexed by output row
+    int top, left, ch, cw;                     // crop window in the resized image
+    int row0, nrows;                           // input rows the cropped output rows read: [row0, row0 + nrows)
+    float mean[3], std[3];
+    unsigned char* tmp;                        // [P, nrows, cw, 3]
+    float* out;
+};
+int pope_launch_preprocess(const PreprocParams& p, hipStream_t stream);
+int pope_launch_gray(const unsigned char* bgr, size_t npix, float* out, hipStream_t stream);

@@ -1,0 +1,107 @@
+// Batched image preprocessing on the GPU: what the reference does per proposal on the host with
+// PIL + torchvision (segment_anything/segment_anything/dinov2_utils.py:55-78: ToPILImage -> Resize((256,256)) ->
+// CenterCrop((196,196)) | Resize((224,224)) -> ToTensor -> Normalize) for P uint8 HWC crops at once, bit-identical to
+// that host path: the resize is Pillow's 8-bit bilinear resample — two separable passes (horizontal, then vertical),
+// per-output-pixel windows with 22-bit fixed-point weights, int32 accumulation from 2^21, each pass rounded to uint8 —
+// with the window / weight tables built on the host in double precision exactly as Pillow builds them
+// (pope_amd/preprocess.py:resize_tables); ToTensor and Normalize are one fp32 division and one fp32 subtract + division.
+// Only the centre-crop window is computed.  Channel order is taken as given (the drivers pass cv2 BGR frames as RGB).
+// HBM-bound streaming kernels: a thread per output pixel, the three channels of a pixel together, coalesced along x.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int PIL_BITS = 22;   // Pillow: PRECISION_BITS = 32 - 8 - 2
+
+__device__ __forceinline__ unsigned char clip8(int v) {
+    v >>= PIL_BITS;
+    return static_cast<unsigned char>(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// horizontal pass over the input rows the vertical pass will need, for the cropped output columns only:
+// tmp[p][r][x][c], r = input row - row0, x = output column - left
+__global__ __launch_bounds__(256) void resize_h_kernel(const unsigned char* __restrict__ img, int P, int Hin, int Win,
+                                                        const int* __restrict__ hstart, const int* __restrict__ hcount,
+                                                        const int* __restrict__ hk, int kh, int row0, int nrows, int left, int cw,
+                                                        unsigned char* __restrict__ tmp) {
+    const size_t total = size_t(P) * nrows * cw;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += size_t(gridDim.x) * 256) {
+        const int x = int(i % cw);
+        const size_t pr = i / cw;
+        const int r = int(pr % nrows), p = int(pr / nrows);
+        const int ox = left + x, s = hstart[ox], n = hcount[ox];
+        const unsigned char* src = img + ((size_t(p) * Hin + row0 + r) * Win + s) * 3;
+        const int* k = hk + size_t(ox) * kh;
+        int a0 = 1 << (PIL_BITS - 1), a1 = a0, a2 = a0;
+        for (int t = 0; t < n; ++t) {
+            const int w = k[t];
+            a0 += int(src[3 * t]) * w;
+            a1 += int(src[3 * t + 1]) * w;
+            a2 += int(src[3 * t + 2]) * w;
+        }
+        unsigned char* o = tmp + i * 3;
+        o[0] = clip8(a0); o[1] = clip8(a1); o[2] = clip8(a2);
+    }
+}
+
+// vertical pass + centre crop + ToTensor (/255) + Normalize ((v - mean) / std), NCHW fp32
+__global__ __launch_bounds__(256) void resize_v_norm_kernel(const unsigned char* __restrict__ tmp, int P, int row0, int nrows,
+                                                             const int* __restrict__ vstart, const int* __restrict__ vcount,
+                                                             const int* __restrict__ vk, int kv, int top, int ch, int cw,
+                                                             float m0, float m1, float m2, float s0, float s1, float s2,
+                                                             float* __restrict__ out) {
+    const size_t total = size_t(P) * ch * cw;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += size_t(gridDim.x) * 256) {
+        const int x = int(i % cw);
+        const size_t py = i / cw;
+        const int y = int(py % ch), p = int(py / ch);
+        const int oy = top + y, s = vstart[oy], n = vcount[oy];
+        const unsigned char* src = tmp + ((size_t(p) * nrows + (s - row0)) * cw + x) * 3;
+        const int* k = vk + size_t(oy) * kv;
+        int a0 = 1 << (PIL_BITS - 1), a1 = a0, a2 = a0;
+        for (int t = 0; t < n; ++t) {
+            const int w = k[t];
+            const unsigned char* q = src + size_t(t) * cw * 3;
+            a0 += int(q[0]) * w;
+            a1 += int(q[1]) * w;
+            a2 += int(q[2]) * w;
+        }
+        const size_t plane = size_t(ch) * cw, o = size_t(p) * 3 * plane + size_t(y) * cw + x;
+        out[o] = (float(clip8(a0)) / 255.0f - m0) / s0;
+        out[o + plane] = (float(clip8(a1)) / 255.0f - m1) / s1;
+        out[o + 2 * plane] = (float(clip8(a2)) / 255.0f - m2) / s2;
+    }
+}
+
+// cv2.cvtColor(BGR2GRAY) for 8-bit images (OpenCV's fixed-point form: B 1868, G 9617, R 4899, 14 fractional bits,
+// round to nearest) followed by `/ 255.` (eval_linemod_json.py:103-111): [P,H,W,3] uint8 BGR -> [P,1,H,W] fp32
+__global__ __launch_bounds__(256) void gray_kernel(const unsigned char* __restrict__ bgr, size_t npix, float* __restrict__ out) {
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < npix; i += size_t(gridDim.x) * 256) {
+        const unsigned char* q = bgr + i * 3;
+        const int g = (int(q[0]) * 1868 + int(q[1]) * 9617 + int(q[2]) * 4899 + (1 << 13)) >> 14;
+        out[i] = float(g) / 255.0f;
+    }
+}
+
+inline unsigned grid_for(size_t n) { return unsigned(n / 256 + 1 < 16384 ? n / 256 + 1 : 16384); }
+
+}  // namespace
+
+int pope_launch_preprocess(const PreprocParams& p, hipStream_t stream) {
+    if (!p.img || !p.out || !p.tmp || !p.hstart || !p.hcount || !p.hk || !p.vstart || !p.vcount || !p.vk) return POPE_ERR_ARG;
+    if (p.P <= 0 || p.Hin <= 0 || p.Win <= 0 || p.ch <= 0 || p.cw <= 0 || p.top < 0 || p.left < 0 || p.kh <= 0 || p.kv <= 0) return POPE_ERR_ARG;
+    if (p.row0 < 0 || p.nrows <= 0 || p.row0 + p.nrows > p.Hin) return POPE_ERR_ARG;
+    hipLaunchKernelGGL(resize_h_kernel, dim3(grid_for(size_t(p.P) * p.nrows * p.cw)), dim3(256), 0, stream, p.img, p.P, p.Hin, p.Win,
+                       p.hstart, p.hcount, p.hk, p.kh, p.row0, p.nrows, p.left, p.cw, p.tmp);
+    hipLaunchKernelGGL(resize_v_norm_kernel, dim3(grid_for(size_t(p.P) * p.ch * p.cw)), dim3(256), 0, stream, p.tmp, p.P, p.row0,
+                       p.nrows, p.vstart, p.vcount, p.vk, p.kv, p.top, p.ch, p.cw, p.mean[0], p.mean[1], p.mean[2], p.std[0],
+                       p.std[1], p.std[2], p.out);
+    return pope_check_launch();
+}
+
+int pope_launch_gray(const unsigned char* bgr, size_t npix, float* out, hipStream_t stream) {
+    if (!bgr || !out || !npix) return POPE_ERR_ARG;
+    hipLaunchKernelGGL(gray_kernel, dim3(grid_for(npix)), dim3(256), 0, stream, bgr, npix, out);
+    return pope_check_launch();
+}

@@ -61,12 +61,17 @@ def _prep(image, resize, crop):
 
 
 def set_torch_image(image: np.ndarray, image_format: str = "RGB", center_crop=False):
-    """dinov2_utils.py:55-78.  HWC uint8 (the drivers pass cv2 BGR as-is) -> [1,3,H,W] on cuda."""
-    if center_crop:
-        t = _prep(image, (256, 256), (196, 196))
-    else:
-        t = _prep(image, (224, 224), None)
-    return t[None, ...].cuda()
+    """dinov2_utils.py:55-78.  HWC uint8 (the drivers pass cv2 BGR as-is) -> [1,3,H,W] on cuda.
+    The uint8 frame is uploaded as it is and resized / cropped / normalised on the GPU (pope_amd/preprocess.py),
+    bit-identical to the PIL + torchvision host path (`_prep` is that host path, kept as the parity reference);
+    `set_torch_images` there takes all proposals of a query at once."""
+    from .preprocess import set_torch_images
+    if isinstance(image, torch.Tensor):
+        image = image.numpy()
+    image = np.asarray(image)
+    if image.ndim == 2:
+        image = np.stack([image] * 3, -1)
+    return set_torch_images(image[None], center_crop=center_crop)
 
 
 def get_cls_token_torch(model, input_tensor):

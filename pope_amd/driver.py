@@ -51,3 +51,18 @@ def locate_and_match(dinov2_model, matcher, ref_tensor, crop_tensors, gray_ref, 
     out["best_slot"] = int(np.argmax(out["matching_score"]))
     out["best_proposal"] = int(slot_index[out["best_slot"]])
     return out
+
+
+@torch.no_grad()
+def locate_and_match_u8(dinov2_model, matcher, ref_bgr, crops_bgr, conf_thr=0.9):
+    """The same step from raw uint8 frames, preprocessing included: `ref_bgr` [H0, W0, 3] and
+    `crops_bgr` [P, 256, 256, 3] uint8 BGR (numpy or tensors), as the drivers hold them after cropping
+    (eval_linemod_json.py:62-64,83-90,103-111).  One upload of the uint8 frames; resize / centre crop / normalisation of
+    all P + 1 DINOv2 inputs and the gray / 255 conversion of all matcher inputs run as batched HIP kernels that are
+    bit-identical to the reference's per-image PIL + torchvision + cv2 host calls (pope_amd/preprocess.py)."""
+    from .preprocess import gray_batch, set_torch_images
+    dev = next(dinov2_model.parameters()).device
+    ref = torch.as_tensor(ref_bgr)[None].to(dev)
+    crops = torch.as_tensor(crops_bgr).to(dev)
+    return locate_and_match(dinov2_model, matcher, set_torch_images(ref, center_crop=True), set_torch_images(crops, center_crop=True),
+                            gray_batch(ref), gray_batch(crops), conf_thr)

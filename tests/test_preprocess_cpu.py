@@ -47,3 +47,20 @@ def test_pairs_by_id_depend_on_the_id_only():
     assert torch.equal(a0[1], b0[0]) and torch.equal(a1[1], b1[0]) and not torch.equal(a0[0], a0[1])
     noise = a1 - torch.roll(a0, (14, 28), (2, 3))
     assert abs(float(noise.std()) - 0.1) < 5e-3 and abs(float(noise.mean())) < 5e-3
+
+
+def test_pil_resize_restatement_is_bit_exact():
+    """oracle/pil_resize_ref.py (the restatement of Pillow's 8-bit bilinear resample) against Pillow itself, and the
+    product's table builder against the oracle's: down- and up-scaling, identity, odd sizes."""
+    from PIL import Image
+    from oracle.pil_resize_ref import resize_bilinear_u8, resize_tables as ref_tables
+    from pope_amd.preprocess import resize_tables
+    rng = np.random.default_rng(0)
+    for (h, w, oh, ow) in [(480, 640, 256, 256), (300, 400, 224, 224), (100, 120, 256, 256), (256, 256, 256, 256),
+                           (513, 257, 256, 256), (37, 41, 224, 224)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        assert np.array_equal(resize_bilinear_u8(img, oh, ow), want), (h, w, oh, ow)
+        for a, b in ((h, oh), (w, ow)):
+            for x, y in zip(resize_tables(a, b), ref_tables(a, b)):
+                assert np.array_equal(x, y)
