@@ -213,6 +213,24 @@ int pope_dense_match_f32(const float* feat0, long long stride0, const float* fea
                          long long* j_ids, float* mconf, float* mkpts0_c, float* mkpts1_c, int* counts,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- LoFTR encoder layer (first slice) ---------------------------------------------------- */
+
+/* LoFTREncoderLayer.forward with LinearAttention — src/matcher/loftr_module/transformer.py:35-58,
+ * linear_attention.py:20-47 (no masks): x[n,L,C] <- x + norm2(mlp(cat[x, norm1(merge(attention(q(x), k(source),
+ * v(source))))])), in place; source[n,S,C] may be x itself ('self' layers).  C = 256 (coarse) or 128 (fine), nhead = 8.
+ * The five bias-free Linears are given as f16x3 WEIGHT planes (layout above): q_wp [C,C], kv_wp [2C,C] (k_proj rows,
+ * then v_proj rows), merge_wp [C,C], mlp0_wp [2C,2C], mlp1_wp [C,2C]; LayerNorm eps = ln_eps (nn.LayerNorm default
+ * 1e-5).  LocalFeatureTransformer.forward (:85-106) is a sequence of these calls: 'self' = (f0,f0),(f1,f1); 'cross' =
+ * (f0,f1) then (f1, NEW f0). */
+typedef struct pope_loftr_layer_weights {
+    const void *q_wp, *kv_wp, *merge_wp, *mlp0_wp, *mlp1_wp;
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+} pope_loftr_layer_weights;
+size_t pope_loftr_layer_workspace_bytes(int n, int L, int S, int C, int nhead);
+int pope_loftr_encoder_layer_f32(const pope_loftr_layer_weights* w_host, float* x, const float* source,
+                                 int n, int L, int S, int C, int nhead, float ln_eps,
+                                 void* workspace, size_t workspace_bytes, unsigned* range_flag, void* stream);
+
 /* ---- caller-side preprocessing, batched ------------------------------------------------- */
 
 /* set_torch_image for P crops at once — segment_anything/segment_anything/dinov2_utils.py:55-78: Resize (Pillow's

@@ -29,6 +29,11 @@ class VitWeights(C.Structure):
                 ("patch_wp", C.c_void_p)]
 
 
+class LoftrLayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("q_wp", "kv_wp", "merge_wp", "mlp0_wp", "mlp1_wp", "norm1_w", "norm1_b", "norm2_w",
+                                           "norm2_b")]
+
+
 # name -> (restype, argtypes); every symbol declared in include/pope_hip.h
 PREC_F32_MFMA, PREC_F16X3 = 0, 1
 PLANES_ACT_SCALE, PLANES_W_SCALE = 8.0, 256.0
@@ -74,6 +79,9 @@ PROTOTYPES = {
     "pope_dense_match_prec_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 8
                                   + [C.c_float, C.c_int, C.c_float, C.c_float] + [C.c_void_p] * 8
                                   + [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "pope_loftr_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
+    "pope_loftr_encoder_layer_f32": (C.c_int, [C.POINTER(LoftrLayerWeights), C.c_void_p, C.c_void_p] + [C.c_int] * 5
+                                     + [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pope_preprocess_u8_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3
                                + [C.c_int] * 7 + [c_float_p, c_float_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pope_gray_u8_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -496,6 +496,24 @@ int pope_dense_match_prec_f32(const float* feat0, long long stride0, const float
     return pope_launch_dense_match_f32(p, static_cast<hipStream_t>(stream));
 }
 
+size_t pope_loftr_layer_workspace_bytes(int n, int L, int S, int C, int nhead) {
+    if (n <= 0 || L <= 0 || S <= 0 || C <= 0 || nhead <= 0) return 0;
+    return pope_loftr_layer_workspace(n, L, S, C, nhead);
+}
+
+int pope_loftr_encoder_layer_f32(const pope_loftr_layer_weights* w, float* x, const float* source, int n, int L, int S, int C,
+                                 int nhead, float ln_eps, void* workspace, size_t workspace_bytes, unsigned* range_flag,
+                                 void* stream) {
+    StreamDevice on_device(stream);
+    if (!w) return POPE_ERR_ARG;
+    LoftrLayerParams p = {};
+    p.x = x; p.source = source; p.n = n; p.L = L; p.S = S; p.C = C; p.H = nhead;
+    p.q_wp = w->q_wp; p.kv_wp = w->kv_wp; p.merge_wp = w->merge_wp; p.mlp0_wp = w->mlp0_wp; p.mlp1_wp = w->mlp1_wp;
+    p.norm1_w = w->norm1_w; p.norm1_b = w->norm1_b; p.norm2_w = w->norm2_w; p.norm2_b = w->norm2_b;
+    p.ln_eps = ln_eps; p.ws = workspace; p.ws_bytes = workspace_bytes; p.range_flag = range_flag;
+    return pope_launch_loftr_layer(p, static_cast<hipStream_t>(stream));
+}
+
 int pope_preprocess_u8_f32(const unsigned char* img_hwc, int P, int Hin, int Win, const int* hstart, const int* hcount,
                            const int* hk, int kh, const int* vstart, const int* vcount, const int* vk, int kv, int top, int left,
                            int ch, int cw, int row0, int nrows, const float* mean_host, const float* std_host, float* out,

@@ -909,6 +909,7 @@ int pope_launch_gemm_nt_f16x3_planes(const GemmParams& g, hipStream_t stream) {
         case EPI_BIAS_LS_RES:
             if (!g.res || out_planes || (!g.gamma && g.res_mod <= 0)) return POPE_ERR_ARG;
             return launch_planes<EPI_BIAS_LS_RES, false>(g, stream);
+        case EPI_BIAS_RELU: return pope_launch_planes16(g, stream);   // 16x16x32 kernel only
     }
     return POPE_ERR_ARG;
 }

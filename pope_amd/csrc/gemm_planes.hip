@@ -333,6 +333,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
                     v = v * inv + bias;
                     const f32x2 g01 = gelu_erf_pair(f32x2{v[0], v[1]}), g23 = gelu_erf_pair(f32x2{v[2], v[3]});
                     v = f32x4{g01[0], g01[1], g23[0], g23[1]};
+                } else if constexpr (EPI == EPI_BIAS_RELU) {
+                    v = v * inv + bias;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(v[e], 0.f);
                 } else {
                     v = res[i] + v * gamma + bias;
                 }
@@ -443,6 +447,7 @@ int pope_launch_planes16(const GemmParams& g, hipStream_t stream) {
     switch (g.epilogue) {
         case EPI_BIAS: return out_planes ? launch16<EPI_BIAS, true>(g, stream) : launch16<EPI_BIAS, false>(g, stream);
         case EPI_BIAS_GELU: return out_planes ? launch16<EPI_BIAS_GELU, true>(g, stream) : launch16<EPI_BIAS_GELU, false>(g, stream);
+        case EPI_BIAS_RELU: return out_planes ? launch16<EPI_BIAS_RELU, true>(g, stream) : launch16<EPI_BIAS_RELU, false>(g, stream);
         case EPI_BIAS_LS_RES: return launch16<EPI_BIAS_LS_RES, false>(g, stream);
         case EPI_SIM: return launch16<EPI_SIM, false>(g, stream, g.nbatch);
     }

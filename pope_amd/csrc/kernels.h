@@ -9,6 +9,7 @@ enum GemmEpilogue {
     EPI_BIAS_GELU = 1,    // C = gelu_erf(A.W^T + bias)
     EPI_BIAS_LS_RES = 2,  // C = res + gamma * (A.W^T + bias)      (LayerScale + residual)
     EPI_POSB = 3,         // patch embed: C = im2col(img).W^T + posb[token]   (A = image)
+    EPI_BIAS_RELU = 5,    // C = max(A.W^T + bias, 0)                (LoFTR encoder MLP, transformer.py:24-28; gemm_planes.hip only)
     EPI_SIM = 4,          // batched similarity (planes kernel): C[b] = (A[b].W[b]^T * alpha) / divisor, no bias
 };
 
@@ -154,3 +155,17 @@ struct PreprocParams {
 };
 int pope_launch_preprocess(const PreprocParams& p, hipStream_t stream);
 int pope_launch_gray(const unsigned char* bgr, size_t npix, float* out, hipStream_t stream);
+
+// One LoFTR encoder layer update (loftr.hip): x <- layer(x, source); weights as f16x3 planes (bias-free Linears)
+struct LoftrLayerParams {
+    float* x;              // [n, L, C] in / out
+    const float* source;   // [n, S, C] (may be x itself: 'self' layers)
+    int n, L, S, C, H;
+    const void *q_wp, *kv_wp, *merge_wp, *mlp0_wp, *mlp1_wp;   // [C,C], [2C,C] (k rows then v rows), [C,C], [2C,2C], [C,2C]
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+    float ln_eps;
+    void* ws; size_t ws_bytes;
+    unsigned* range_flag;
+};
+size_t pope_loftr_layer_workspace(int n, int L, int S, int C, int H);
+int pope_launch_loftr_layer(const LoftrLayerParams& p, hipStream_t stream);

@@ -175,7 +175,9 @@ def linear_attention(q, k, v, eps=1e-6):
 
 
 class LoFTREncoderLayer(nn.Module):
-    """loftr_module/transformer.py:7-58."""
+    """loftr_module/transformer.py:7-58.  On CUDA tensors the layer update is ONE call into the HIP library
+    (pope_loftr_encoder_layer_f32: five f16x3 planes GEMMs + the O(L) linear-attention kernels + both LayerNorms);
+    the torch form below is the CPU restatement used by the `-m "not gpu"` tests."""
 
     def __init__(self, d_model, nhead, attention="linear"):
         super().__init__()
@@ -190,6 +192,52 @@ class LoFTREncoderLayer(nn.Module):
                                  nn.Linear(2 * d_model, d_model, bias=False))
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
+        self._hip = None
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._hip = None
+        return out
+
+    def load_state_dict(self, *a, **k):
+        self._hip = None
+        return super().load_state_dict(*a, **k)
+
+    def _hip_weights(self):
+        """ctypes struct of the layer's weights: the five bias-free Linears as f16x3 weight planes (range-checked),
+        LayerNorm parameters as they are.  None when a weight leaves the f16x3 range (the torch form then runs)."""
+        from . import _lib
+        key = self.q_proj.weight.data_ptr()
+        if self._hip is not None and self._hip[0] == key:
+            return self._hip[1]
+        lin = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.merge.weight, self.mlp[0].weight, self.mlp[2].weight]
+        amax = float(torch.stack([t.detach().abs().max() for t in lin]).max())
+        if not amax * _lib.PLANES_W_SCALE < _lib.F16_MAX:
+            self._hip = (key, None, None)
+            return None
+        keep = [_lib.to_planes(self.q_proj.weight, _lib.PLANES_W_SCALE),
+                _lib.to_planes(torch.cat([self.k_proj.weight.detach(), self.v_proj.weight.detach()], 0), _lib.PLANES_W_SCALE),
+                _lib.to_planes(self.merge.weight, _lib.PLANES_W_SCALE),
+                _lib.to_planes(self.mlp[0].weight, _lib.PLANES_W_SCALE), _lib.to_planes(self.mlp[2].weight, _lib.PLANES_W_SCALE)]
+        norms = [t.detach().float().contiguous() for t in (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias)]
+        w = _lib.LoftrLayerWeights(*[t.data_ptr() for t in keep + norms])
+        self._hip = (key, w, keep + norms)
+        return w
+
+    def update_(self, x, source, workspace):
+        """In-place HIP layer update of `x` [n, L, C] (fp32, contiguous, CUDA) against `source` (may be `x`)."""
+        import ctypes as C
+        from . import _lib
+        w = self._hip_weights()
+        n, L, Cd = x.shape
+        S = source.shape[1]
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        with _lib.on_device_of(x):
+            _lib.check(_lib.lib().pope_loftr_encoder_layer_f32(
+                C.byref(w), C.c_void_p(x.data_ptr()), C.c_void_p(source.data_ptr()), n, L, S, Cd, self.nhead,
+                float(self.norm1.eps), C.c_void_p(workspace.data_ptr()), workspace.numel(), C.c_void_p(flag.data_ptr()),
+                _lib.stream_of(x.device)), "pope_loftr_encoder_layer_f32")
+        return flag
 
     def forward(self, x, source, x_mask=None, source_mask=None):
         if x_mask is not None or source_mask is not None:
@@ -204,7 +252,8 @@ class LoFTREncoderLayer(nn.Module):
 
 class LocalFeatureTransformer(nn.Module):
     """loftr_module/transformer.py:61-106; 'cross' layers update feat0 first and feed the NEW feat0 into
-    the feat1 update (:101-102)."""
+    the feat1 update (:101-102).  CUDA inputs run on the HIP encoder layer (f16x3 planes GEMMs, guarded: if a weight or
+    an activation leaves the f16x3 range the whole transformer is re-run in torch fp32, with a warning)."""
 
     def __init__(self, config):
         super().__init__()
@@ -215,19 +264,58 @@ class LocalFeatureTransformer(nn.Module):
         for p in self.parameters():  # transformer.py:77-80
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
+        self.use_hip = True   # dev / test switch: False = the torch form on any device
 
-    def forward(self, feat0, feat1, mask0=None, mask1=None):
-        assert self.d_model == feat0.size(2), "the feature number of src and transformer must be equal"
+    def _forward_torch(self, feat0, feat1):
         for layer, name in zip(self.layers, self.layer_names):
             if name == "self":
-                feat0 = layer(feat0, feat0, mask0, mask0)
-                feat1 = layer(feat1, feat1, mask1, mask1)
+                feat0 = layer(feat0, feat0)
+                feat1 = layer(feat1, feat1)
             elif name == "cross":
-                feat0 = layer(feat0, feat1, mask0, mask1)
-                feat1 = layer(feat1, feat0, mask1, mask0)
+                feat0 = layer(feat0, feat1)
+                feat1 = layer(feat1, feat0)
             else:
                 raise KeyError(name)
         return feat0, feat1
+
+    def _forward_hip(self, feat0, feat1):
+        from . import _lib
+        if self.d_model not in (128, 256) or self.nhead != 8 or any(l._hip_weights() is None for l in self.layers):
+            return None
+        for name in self.layer_names:
+            if name not in ("self", "cross"):
+                raise KeyError(name)
+        f0, f1 = feat0.float().contiguous().clone(), feat1.float().contiguous().clone()
+        n, L, C = f0.shape
+        S = f1.shape[1]
+        lib = _lib.lib()
+        nbytes = max(lib.pope_loftr_layer_workspace_bytes(n, a, b, C, self.nhead) for a in (L, S) for b in (L, S))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=f0.device)
+        flags = []
+        for layer, name in zip(self.layers, self.layer_names):
+            if name == "self":
+                flags.append(layer.update_(f0, f0, ws))
+                flags.append(layer.update_(f1, f1, ws))
+            else:
+                flags.append(layer.update_(f0, f1, ws))
+                flags.append(layer.update_(f1, f0, ws))
+        bits = int(torch.stack(flags).max())   # one synchronisation per transformer
+        if bits:
+            import warnings
+            warnings.warn(f"pope_amd: f16x3 range contract breached in the LoFTR transformer ({_lib.describe_range_bits(bits)}); "
+                          "re-running it in torch fp32")
+            return None
+        return f0, f1
+
+    def forward(self, feat0, feat1, mask0=None, mask1=None):
+        assert self.d_model == feat0.size(2), "the feature number of src and transformer must be equal"
+        if mask0 is not None or mask1 is not None:
+            raise NotImplementedError("pope_amd: padding masks are a training-time path (matcher.py:62-64)")
+        if self.use_hip and feat0.is_cuda and feat0.shape[0] > 0:
+            out = self._forward_hip(feat0, feat1)
+            if out is not None:
+                return out
+        return self._forward_torch(feat0, feat1)
 
 
 # ------------------------------------------------------------------------------------- fine stage

@@ -123,3 +123,67 @@ def test_no_coarse_match_short_circuit(dev):
     assert data["b_ids"].numel() == 0 and data["expec_f"].shape == (0, 3)
     assert data["mkpts0_f"].shape == (0, 2) and data["mkpts1_f"].shape == (0, 2)
     assert data["conf_matrix"].shape == (1, 96, 96)
+
+
+# ---- the HIP LoFTR encoder layer (first slice) -----------------------------------------------------
+
+def _transformer(kind, dev, seed=0):
+    from pope_amd import synth
+    from pope_amd.loftr import LocalFeatureTransformer
+    from pope_amd.matcher import default_cfg
+    t = LocalFeatureTransformer(default_cfg[kind]).eval()
+    prefix = "loftr_coarse." if kind == "coarse" else "loftr_fine."
+    sd = synth.synthetic_matcher_state_dict(seed=seed)
+    t.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, strict=True)
+    return t.to(dev)
+
+
+@pytest.mark.parametrize("kind,n,L,S", [("coarse", 2, 1024, 1024), ("coarse", 3, 768, 1024), ("coarse", 1, 4800, 4800),
+                                        ("fine", 153, 25, 25), ("fine", 1, 25, 25)])
+def test_hip_encoder_matches_fp64_restatement(dev, kind, n, L, S):
+    """LocalFeatureTransformer on the HIP layer (f16x3 planes GEMMs + O(L) linear attention + fused LayerNorms) against
+    the same module evaluated in float64 on the CPU (transformer.py:85-106 semantics: 'cross' feeds the NEW feat0)."""
+    t = _transformer(kind, dev)
+    C = t.d_model
+    g = torch.Generator().manual_seed(L + S + n)
+    f0, f1 = torch.randn(n, L, C, generator=g), torch.randn(n, S, C, generator=g)
+    ref = copy.deepcopy(t).cpu().double()
+    ref.use_hip = False
+    with torch.no_grad():
+        w0, w1 = ref(f0.double(), f1.double())
+        g0, g1 = t(f0.to(dev), f1.to(dev))
+        t.use_hip = False
+        p0, p1 = t(f0.to(dev), f1.to(dev))     # the torch / rocBLAS plumbing this replaces
+    e_hip = max(float((g0.cpu().double() - w0).abs().max()), float((g1.cpu().double() - w1).abs().max()))
+    e_torch = max(float((p0.cpu().double() - w0).abs().max()), float((p1.cpu().double() - w1).abs().max()))
+    scale = float(w0.abs().max())
+    print(f"{kind} n={n} L={L} S={S}: max err HIP {e_hip:.2e}, torch fp32 {e_torch:.2e}, |feat| max {scale:.2f}")
+    assert e_hip < 2e-4 * max(1.0, scale)
+    assert e_hip < 4 * e_torch + 2e-5        # fp32-equivalent: not worse than the fp32 library path it replaces
+    assert g0.shape == (n, L, C) and g1.shape == (n, S, C) and bool(torch.isfinite(g0).all())
+
+
+def test_hip_encoder_is_deterministic_and_batch_invariant(dev):
+    t = _transformer("coarse", dev)
+    g = torch.Generator().manual_seed(4)
+    f0, f1 = torch.randn(3, 320, 256, generator=g).to(dev), torch.randn(3, 256, 256, generator=g).to(dev)
+    with torch.no_grad():
+        a0, a1 = t(f0, f1)
+        b0, b1 = t(f0, f1)
+        c0, c1 = t(f0[1:2], f1[1:2])
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    assert torch.equal(a0[1:2], c0) and torch.equal(a1[1:2], c1)
+    assert f0.data_ptr() != a0.data_ptr()      # inputs are not modified
+
+
+def test_hip_encoder_range_guard_falls_back(dev):
+    t = _transformer("coarse", dev)
+    g = torch.Generator().manual_seed(5)
+    f0, f1 = torch.randn(1, 128, 256, generator=g).to(dev), torch.randn(1, 128, 256, generator=g).to(dev)
+    f0[0, 7, 3] = 2.0e4                         # |x| * 8 >= 65504
+    with torch.no_grad(), pytest.warns(UserWarning, match="LoFTR transformer"):
+        a0, a1 = t(f0, f1)
+    t.use_hip = False
+    with torch.no_grad():
+        b0, b1 = t(f0, f1)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
