@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the short strict-fp32 leg of the N = 1 run")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="profiling only: skip the self-check (its batch-1 launches would enter rocprof's per-kernel averages); "
+                         "the line then carries \"verified\": null")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the ViT chunks of a step are spread over")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="dev: run the N-rank code path with every rank on cuda:0 and the gloo backend (collectives on "
@@ -277,7 +280,7 @@ def main():
     else:
         v_img0, v_img1 = img0, img1
         picks = sorted({0, args.pairs // 2, args.pairs - 1})
-    failures = verify_step(model, v_img0, v_img1, out, picks)
+    failures = [] if args.no_verify else verify_step(model, v_img0, v_img1, out, picks)
     if counts.numel() != pairs_per_step_total:
         failures.append(f"gathered {counts.numel()} counts for {pairs_per_step_total} pairs")
     if model.overflow_events:
@@ -285,7 +288,7 @@ def main():
     ok = torch.tensor([0 if failures else 1], dtype=torch.int32, device=coll_device)
     if world > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    verified = bool(int(ok))
+    verified = None if args.no_verify else bool(int(ok))
 
     total_pairs = pairs_per_step_total * args.steps
     value = total_pairs / elapsed
@@ -336,7 +339,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
-    if not verified:
+    if verified is False:
         raise SystemExit(3)
 
 

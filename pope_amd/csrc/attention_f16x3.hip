@@ -492,6 +492,9 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
             c0[i] = __builtin_amdgcn_exp2f(c0[i] - sm_shift);
             c1[i] = __builtin_amdgcn_exp2f(c1[i] - sm_shift);
             sm_ls += f32x2{c0[i], c1[i]};
+            // pin the running sum to its slot: the optimiser otherwise sinks the whole (dependent) chain of adds out of
+            // the MFMA shadow to the top of the next iteration, right behind the barrier, one s_nop per add
+            asm volatile("" : "+v"(sm_ls));
         } else {
             l_run += sm_ls;
         }

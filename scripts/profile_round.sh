@@ -8,8 +8,11 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_profiled.json
-echo "stats pass done"
+# (a) the default command as the driver runs it (self-check launches and the strict-fp32 leg included), (b) the f16x3 step
+# alone: per-kernel averages that can be compared with the line's HIP-event figures
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_default -o bench -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_profiled_default.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strict-f32 --no-verify > $OUT/bench_profiled.json
+echo "stats passes done"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" \
             "TCC_HIT_sum TCC_MISS_sum"; do
@@ -22,6 +25,7 @@ python3 scripts/pmc_summary.py $(find $OUT/pmc_* -name '*counter_collection.csv'
 # keep the summaries only: the raw traces exceed what gpurun copies back
 mkdir -p $OUT/profile_round
 cp $(find $OUT/prof_stats -name '*kernel_stats.csv') $OUT/profile_round/bench_kernel_stats.csv
-mv $OUT/pmc_summary.txt $OUT/bench_profiled.json $OUT/profile_round/
-rm -rf $OUT/prof_stats $OUT/pmc_*
+cp $(find $OUT/prof_stats_default -name '*kernel_stats.csv') $OUT/profile_round/bench_default_kernel_stats.csv
+mv $OUT/pmc_summary.txt $OUT/bench_profiled.json $OUT/bench_profiled_default.json $OUT/profile_round/
+rm -rf $OUT/prof_stats $OUT/prof_stats_default $OUT/pmc_*
 echo "profile_round done"
