@@ -437,8 +437,9 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         f.k1l = *reinterpret_cast<const f16x8*>(kb_h + K_PLANE + 32 * KST);
     };
     auto qk_step = [&](int kg, int j, const KFrag& f, f32x16& d0, f32x16& d1) {  // MFMA j (0..5) of d step kg
-        if (j == 0) d0 = mfma_f16(f.k0l, qh[kg], d0);
-        if (j == 1) d1 = mfma_f16(f.k1l, qh[kg], d1);
+        const f32x16 zero = {};  // the first MFMA of a chain starts from the inline-constant C operand: no zero fill
+        if (j == 0) d0 = mfma_f16(f.k0l, qh[kg], kg == 0 ? zero : d0);
+        if (j == 1) d1 = mfma_f16(f.k1l, qh[kg], kg == 0 ? zero : d1);
         if (j == 2) d0 = mfma_f16(f.k0h, ql[kg], d0);
         if (j == 3) d1 = mfma_f16(f.k1h, ql[kg], d1);
         if (j == 4) d0 = mfma_f16(f.k0h, qh[kg], d0);
@@ -452,52 +453,93 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
             if (key + 32 >= N) d1[i] = -INFINITY;
         }
     };
-    // Slice `slot` (0..23) of the online softmax of (c0, c1), in place (log2 domain; p' = 2^(s - m + 10)).  o and l
-    // are rescaled unconditionally (alpha == 1 exactly when the row maximum did not move): no branch in the phase.
-    float sm_mt = 0.f, sm_alpha = 0.f, sm_shift = 0.f;
+    // Online softmax of (c0, c1) with a LAZY reference (log2 domain): p' = 2^(s - m_ref + 8), where m_ref is the row
+    // maximum as of the last exact pass, not of this tile.  On gfx950 every VALU instruction issued between the MFMAs
+    // takes about two cycles from the matrix pipe (DESIGN.md finding 4), so the per-tile row maximum (16 v_max3, the
+    // swap across the two 32-lane halves, its wait states) and the unconditional rescale of o and l (21 multiplies)
+    // are the part of the softmax that can go: a tile whose scores stay below m_ref + 8 needs neither — p' < 2^16
+    // still splits into f16 (hi, lo), and with at least 2^8 of headroom under the running maximum the split keeps
+    // fp32 accuracy.  The tile's probability sum (computed anyway) tells: any p' >= 65 504 makes it >= 65 504.  Only
+    // then — and for NaN/inf — `redo_tile` recomputes the tile's scores from its K stage (still resident) and takes
+    // the exact pass: true row maximum, rescale, new m_ref.  Results never depend on which path ran beyond fp32
+    // rounding; the speed does (diffuse attention rows: exact pass on tile 0 only).
+    constexpr float LAZY_HEADROOM = 8.0f, LAZY_LIMIT = 65504.0f;
+    float sm_shift = 0.f;
     f32x2 sm_ls = {0.f, 0.f};
+    auto exact_prepare = [&](const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {  // true row maximum of the raw scores -> m_run; o, l rescaled
+        float mt = vmax3(c0[0], c1[0], c0[1]);
+#pragma unroll
+        for (int i = 1; i < 15; ++i) mt = vmax3(mt, c1[i], c0[i + 1]);
+        mt = __builtin_fmaxf(mt, c1[15]);   // compiler-generated: feeds the permlane swap
+        // the row maximum lives in lanes l and l ^ 32: v_permlane32_swap hands each half the other's value in one
+        // instruction (a __shfl_xor is a ds_bpermute: 7 address instructions, an LDS round trip and a wait).  Its
+        // operand and its results are touched by COMPILER-generated instructions only: the hazard recognizer does
+        // not look into inline asm, and VALU write -> permlane swap -> VALU read need wait states on gfx950.
+        float ma, mb;
+        pope_xor32_pair(mt, ma, mb);
+        const float m_new = __builtin_fmaxf(m_run, __builtin_fmaxf(ma, mb));
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: 2^(-inf) = 0 on o = l = 0
+        m_run = m_new;
+        sm_shift = m_new - LAZY_HEADROOM;
+        l_run = l_run * alpha;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+    };
+    auto exp_pair = [&](int i, f32x16& c0, f32x16& c1) __attribute__((always_inline)) {
+        // in place, and the two of a packed add adjacent in their tuple: pairing c0[i] with c1[i] makes the register
+        // allocator permute the tuples for the v_pk_add and copy them back (24 v_mov per tile)
+        f32x16& c = i < 8 ? c0 : c1;
+        const int e = 2 * (i & 7);
+        c[e] = __builtin_amdgcn_exp2f(c[e] - sm_shift);
+        c[e + 1] = __builtin_amdgcn_exp2f(c[e + 1] - sm_shift);
+        sm_ls += f32x2{c[e], c[e + 1]};
+        // pin the running sum to its slot: the optimiser otherwise sinks the whole (dependent) chain of adds out of
+        // the MFMA shadow to the top of the next iteration, right behind the barrier, one s_nop per add
+        asm volatile("" : "+v"(sm_ls));
+    };
+    // slice `slot` (0..23) of the fast pass: two probabilities of each sub-tile in two of every three slots
     auto softmax_slice = [&](int slot, auto ptag) {
+#ifdef ATTN_ABL_NOSOFTMAX  // dev ablation (wrong results): what the phase costs without its VALU work
+        return;
+#endif
+        if (slot == 0) sm_ls = f32x2{0.f, 0.f};
+        if (slot % 3 != 2) exp_pair((slot / 3) * 2 + slot % 3, sb[decltype(ptag)::value][0], sb[decltype(ptag)::value][1]);
+    };
+    // the exact pass for tile `tile` (its K rows in stage st): scores again, true maximum, rescale, probabilities
+    auto redo_tile = [&](int tile, int st, auto ptag) __attribute__((always_inline)) {
         f32x16& c0 = sb[decltype(ptag)::value][0];
         f32x16& c1 = sb[decltype(ptag)::value][1];
-        if (slot == 0) {
-            sm_mt = vmax3(c0[0], c1[0], c0[1]);
+        f32x16 d0, d1;
+        KFrag kf;
 #pragma unroll
-            for (int i = 1; i < 8; ++i) sm_mt = vmax3(sm_mt, c1[i], c0[i + 1]);
-        } else if (slot == 1) {
+        for (int kg = 0; kg < 4; ++kg) {
+            read_kfrag(st, kg, kf);
 #pragma unroll
-            for (int i = 8; i < 15; ++i) sm_mt = vmax3(sm_mt, c1[i], c0[i + 1]);
-            sm_mt = __builtin_fmaxf(sm_mt, c1[15]);   // compiler-generated: feeds the permlane swap of slot 2
-        } else if (slot == 2) {
-            // the row maximum lives in lanes l and l ^ 32: v_permlane32_swap hands each half the other's value in one
-            // instruction (a __shfl_xor is a ds_bpermute: 7 address instructions, an LDS round trip and a wait).  Its
-            // operand and its results are touched by COMPILER-generated instructions only: the hazard recognizer does
-            // not look into inline asm, and VALU write -> permlane swap -> VALU read need wait states on gfx950.
-            float ma, mb;
-            pope_xor32_pair(sm_mt, ma, mb);
-            const float m_new = __builtin_fmaxf(m_run, __builtin_fmaxf(ma, mb));
-            sm_alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            sm_shift = m_new - 10.0f;
-            l_run = l_run * sm_alpha;
-            sm_ls = f32x2{0.f, 0.f};
-        } else if (slot < 7) {  // 3..6: a quarter of the output accumulators each
-            const int q = slot - 3;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (q < 2) o0[8 * q + e] *= sm_alpha;
-                else o1[8 * (q - 2) + e] *= sm_alpha;
-            }
-        } else if (slot < 23) {  // 7..22: two probabilities of each sub-tile (packing adjacent pairs was slower)
-            const int i = slot - 7;
-            c0[i] = __builtin_amdgcn_exp2f(c0[i] - sm_shift);
-            c1[i] = __builtin_amdgcn_exp2f(c1[i] - sm_shift);
-            sm_ls += f32x2{c0[i], c1[i]};
-            // pin the running sum to its slot: the optimiser otherwise sinks the whole (dependent) chain of adds out of
-            // the MFMA shadow to the top of the next iteration, right behind the barrier, one s_nop per add
-            asm volatile("" : "+v"(sm_ls));
-        } else {
-            l_run += sm_ls;
+            for (int j = 0; j < 6; ++j) qk_step(kg, j, kf, d0, d1);
         }
+        if ((tile + 1) * KT > N) mask_tail(tile, d0, d1);
+        // hand the scores back IN the registers the fast pass uses ("+v" ties them): a plain assignment makes the
+        // register allocator merge the two paths with copies on the fast one.  The s_nops: XDL write -> VALU read
+        // wait states the hazard recognizer does not add for inline asm
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(d0), "+v"(d1));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            asm volatile("v_mov_b32 %0, %1" : "+v"(c0[i]) : "v"(d0[i]));
+            asm volatile("v_mov_b32 %0, %1" : "+v"(c1[i]) : "v"(d1[i]));
+        }
+        exact_prepare(c0, c1);
+        sm_ls = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) exp_pair(i, c0, c1);
+    };
+    // after the fast pass of a tile: did every probability fit?  (wave-uniform branch; !(x < limit) also catches NaN)
+    auto settle = [&](int tile, int st, auto ptag) __attribute__((always_inline)) {
+#ifdef ATTN_ABL_NOSOFTMAX
+        return;
+#endif
+        const float tile_sum = sm_ls[0] + sm_ls[1];
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(tile_sum < LAZY_LIMIT)) != 0, 0)) redo_tile(tile, st, ptag);
+        l_run += sm_ls;
     };
     // ---- phase 1: S^T(tile in stage st_next) -> (n0, n1), each MFMA followed by a slice of the softmax of (c0, c1)
     auto phase1 = [&](int st_next, auto ptag) {
@@ -505,8 +547,6 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         f32x16& n1 = sb[decltype(ptag)::value ^ 1][1];
         KFrag kf[2];
         read_kfrag(st_next, 0, kf[0]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { n0[i] = 0.f; n1[i] = 0.f; }
 #pragma unroll
         for (int i = 0; i < 24; ++i) {
             const int kg = i / 6, j = i % 6;
@@ -523,12 +563,10 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     // ---- phase 2: O^T += V^T(stage st) . P^T with P = (c0, c1); the hi/lo split of the next 16 keys' probabilities
     // (and, SPLIT_KV, of one K/V row of tile t+2 per group) sits behind the MFMAs of the current 16 keys
     auto split_group = [&](int g, int half, f16x4& hi, f16x4& lo, auto ptag) {
-        const f32x16& c0 = sb[decltype(ptag)::value][0];
-        const f32x16& c1 = sb[decltype(ptag)::value][1];
         const int u = g >> 1, s2 = g & 1;
         f32x4 pv4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pv4[e] = (u ? c1 : c0)[8 * s2 + 4 * half + e];
+        for (int e = 0; e < 4; ++e) pv4[e] = sb[decltype(ptag)::value][u][8 * s2 + 4 * half + e];
         split4(pv4, hi, lo);
     };
     auto phase2 = [&](int st, int st_write, auto split_tag, const u32x4 (&pregs)[4], auto ptag) {
@@ -536,31 +574,36 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         const _Float16* Vh = lds + st * STAGE_H + 2 * K_PLANE;
         const _Float16* Vl = Vh + V_PLANE;
         f16x4 h0[2], l0[2], h1[2], l1[2];
-        f16x8 vf[2][4];
+        // V fragments: the hi planes double-buffered one 16-key group ahead; the lo planes (needed by the first two
+        // MFMAs of a group only) in ONE buffer that is refilled for the next group right behind those two — 8 VGPRs
+        // less than double-buffering both, which is what keeps the tile loads in flight out of scratch
+        f16x8 vh[2][2], vl[2];
         split_group(0, 0, h0[0], l0[0], ptag);
         split_group(0, 1, h1[0], l1[0], ptag);
-        vf[0][0] = vfrag(Vh, 0, 0, 0); vf[0][1] = vfrag(Vl, 0, 0, 0);
-        vf[0][2] = vfrag(Vh, 0, 0, 1); vf[0][3] = vfrag(Vl, 0, 0, 1);
+        vh[0][0] = vfrag(Vh, 0, 0, 0); vl[0] = vfrag(Vl, 0, 0, 0);
+        vh[0][1] = vfrag(Vh, 0, 0, 1); vl[1] = vfrag(Vl, 0, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 24; ++i) {
             const int g = i / 6, j = i % 6, cur = g & 1, nxt = cur ^ 1;
-            if (j == 0 && g < 3) {
-                const int u = (g + 1) >> 1, s2 = (g + 1) & 1;
-                vf[nxt][0] = vfrag(Vh, u, s2, 0); vf[nxt][1] = vfrag(Vl, u, s2, 0);
-                vf[nxt][2] = vfrag(Vh, u, s2, 1); vf[nxt][3] = vfrag(Vl, u, s2, 1);
-            }
+            const int u = (g + 1) >> 1, s2 = (g + 1) & 1;
+            if (j == 0 && g < 3) { vh[nxt][0] = vfrag(Vh, u, s2, 0); vh[nxt][1] = vfrag(Vh, u, s2, 1); }
             const f16x8 ph = cat(h0[cur], h1[cur]), pl = cat(l0[cur], l1[cur]);
-            if (j == 0) o0 = mfma_f16(vf[cur][1], ph, o0);
-            if (j == 1) o1 = mfma_f16(vf[cur][3], ph, o1);
-            if (j == 2) o0 = mfma_f16(vf[cur][0], pl, o0);
-            if (j == 3) o1 = mfma_f16(vf[cur][2], pl, o1);
-            if (j == 4) o0 = mfma_f16(vf[cur][0], ph, o0);
-            if (j == 5) o1 = mfma_f16(vf[cur][2], ph, o1);
+            if (j == 0) o0 = mfma_f16(vl[0], ph, o0);
+            if (j == 1) o1 = mfma_f16(vl[1], ph, o1);
+            if (j == 2) o0 = mfma_f16(vh[cur][0], pl, o0);
+            if (j == 3) o1 = mfma_f16(vh[cur][1], pl, o1);
+            if (j == 4) o0 = mfma_f16(vh[cur][0], ph, o0);
+            if (j == 5) o1 = mfma_f16(vh[cur][1], ph, o1);
+            if (j == 2 && g < 3) { vl[0] = vfrag(Vl, u, s2, 0); vl[1] = vfrag(Vl, u, s2, 1); }
+#ifdef ATTN_ABL_NOSPLIT
+            if (j == 1) { h0[nxt] = h0[cur]; l0[nxt] = l0[cur]; h1[nxt] = h1[cur]; l1[nxt] = l1[cur]; }
+#else
             if (g < 3) {
                 if (j == 1) split_group(g + 1, 0, h0[nxt], l0[nxt], ptag);
                 if (j == 3) split_group(g + 1, 1, h1[nxt], l1[nxt], ptag);
             }
+#endif
             if (SPLIT_KV && j == 5) {  // a quarter of tile t+2's staging per 16-key group
                 if constexpr (IN_PLANES) {
                     write_chunk(st_write, g, pregs);
@@ -592,8 +635,6 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     {
         KFrag kf;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { sb[0][0][i] = 0.f; sb[0][1][i] = 0.f; }
-#pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             read_kfrag(0, kg, kf);
 #pragma unroll
@@ -612,6 +653,7 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     }
     __syncthreads();
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sb[0][0]), "+v"(sb[0][1]));  // XDL write -> asm VALU read (vmax3) wait states
+    exact_prepare(sb[0][0], sb[0][1]);  // tile 0 sets the first reference
 
     // stage of tile t = t % 3
     int st_cur = 0, st_next = 1, st_write = 2, t = 0;
@@ -621,12 +663,15 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     auto steady = [&](u32x4 (&regs)[4], auto ptag) {
         ATTN_STAMP(t, 0);
         phase1(st_next, ptag);
+        settle(t, st_cur, ptag);
         ATTN_STAMP(t, 1);
         phase2(st_cur, st_write, std::true_type{}, regs, ptag);  // also moves tile t+2 from registers into stage st_write
         if constexpr (IN_PLANES) load_planes(t + 4, regs);
         else if (t + 3 < nkt) load_kv(t + 3);
         ATTN_STAMP(t, 2);
+#ifndef ATTN_ABL_NOBAR
         __syncthreads();  // tile t+2 is published; every wave is done with stage st_cur
+#endif
         ATTN_STAMP(t, 3);
         rotate();
         ++t;
@@ -643,13 +688,16 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
             phase1(st_next, ptag);
             mask_tail(t + 1, sb[P ^ 1][0], sb[P ^ 1][1]);
             asm volatile("" : "+v"(sb[P ^ 1][0]), "+v"(sb[P ^ 1][1]));
+            settle(t, st_cur, ptag);
             phase2(st_cur, st_write, std::false_type{}, pa, ptag);
             rotate();
             ++t;
             softmax_only(Q{});  // last tile
+            settle(t, st_cur, Q{});
             phase2(st_cur, st_write, std::false_type{}, pa, Q{});
         } else {
             softmax_only(ptag);
+            settle(t, st_cur, ptag);
             phase2(st_cur, st_write, std::false_type{}, pa, ptag);
         }
     };

@@ -5,7 +5,7 @@ from pope_amd import ops, _lib
 dev = torch.device("cuda:0")
 B, N, H = 64, 1531, 6
 qkv = torch.randn(B, N, 3 * H * 64, device=dev)
-lib = C.CDLL(os.path.join(os.path.dirname(_lib.__file__), "csrc", "libpope_hip.so"))
+lib = C.CDLL(_lib.LIB_PATH)
 names = ["phase1 (QK next + softmax)", "phase2 (PV + splits + kv store)", "wait barrier"]
 def report(tag):
     torch.cuda.synchronize()

@@ -188,6 +188,45 @@ def test_attention_planes_in_planes_out(dev, hip_lib, B, N, heads, spike):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("step", [0.7, 2.0, 4.5, 9.0, -3.0])
+@pytest.mark.parametrize("planes", [False, True])
+def test_attention_lazy_reference_paths(dev, hip_lib, step, planes):
+    """The f16x3 kernel exponentiates against a LAZY reference (the row maximum of the last exact pass) and takes the
+    exact pass again only when a tile's probabilities would leave the f16 range.  Scores that climb by `step` (natural
+    log units) per 64-key tile drive every mix of the two paths: never again after tile 0 (falling or slowly rising
+    scores), every third / second tile, every tile.  Result must not depend on the path: fp64 reference."""
+    import ctypes as C
+    from pope_amd import ops, _lib
+    B, N, heads = 1, 520, 6          # 9 key tiles, the last one ragged
+    D = heads * 64
+    g = torch.Generator().manual_seed(123)
+    qkv = torch.randn(B, N, 3, heads, 64, generator=g) * 0.3
+    u = torch.randn(heads, 64, generator=g)
+    u = u / u.norm(dim=-1, keepdim=True) * 8.0                      # |u|^2 / 8 = 8: score = 8 * ramp + noise
+    ramp = torch.arange(N, dtype=torch.float32) / 64.0 * (step / 8.0)
+    qkv[0, :, 0] += u                                               # every query looks along u
+    qkv[0, :, 1] += u * ramp[:, None, None]                          # key j: score grows by `step` per 64 keys
+    qkv = qkv.reshape(B, N, 3 * D).contiguous()
+    if planes:
+        pl = _lib.to_planes(qkv.reshape(B * N, 3 * D), _lib.PLANES_ACT_SCALE)
+        seen = _lib.from_planes(pl, _lib.PLANES_ACT_SCALE).double().reshape(B, N, 3 * D)
+    else:
+        seen = qkv.double()
+    q, k, v = seen.reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    want = (((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B * N, D)
+    if planes:
+        pin = pl.to(dev)
+        pout = torch.zeros(B * N, D // 32, 2, 32, dtype=torch.float16, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert hip_lib.pope_attention_planes_f32(C.c_void_p(pin.data_ptr()), C.c_void_p(pout.data_ptr()), B, N, heads, st) == 0
+        got = _lib.from_planes(pout.cpu(), _lib.PLANES_ACT_SCALE).double()
+    else:
+        got = ops.attention(qkv.to(dev), heads, precision="f16x3").cpu().double().reshape(B * N, D)
+    err = float(((got - want).abs() / (1.0 + want.abs())).max())
+    print(f"lazy-reference attention step={step} planes={planes}: max scaled |err| vs fp64 = {err:.2e}")
+    assert err < 2e-5, err
+
+
 def test_cls_cosine_and_top3(dev, golden_dir):
     import os
     from pope_amd import ops
