@@ -425,8 +425,11 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     using P1 = std::integral_constant<int, 1>;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m_run = -INFINITY;
     f32x2 l_run = {0.f, 0.f};
+    // the softmax reference of the rows (see below), negated, in every element: the C operand the score MFMAs start from
+    f32x16 nref;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) nref[i] = INFINITY;
 
     struct KFrag { f16x8 k0h, k0l, k1h, k1l; };
     auto read_kfrag = [&](int st, int kg, KFrag& f) {
@@ -436,10 +439,13 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         f.k1h = *reinterpret_cast<const f16x8*>(kb_h + 32 * KST);
         f.k1l = *reinterpret_cast<const f16x8*>(kb_h + K_PLANE + 32 * KST);
     };
-    auto qk_step = [&](int kg, int j, const KFrag& f, f32x16& d0, f32x16& d1) {  // MFMA j (0..5) of d step kg
-        const f32x16 zero = {};  // the first MFMA of a chain starts from the inline-constant C operand: no zero fill
-        if (j == 0) d0 = mfma_f16(f.k0l, qh[kg], kg == 0 ? zero : d0);
-        if (j == 1) d1 = mfma_f16(f.k1l, qh[kg], kg == 0 ? zero : d1);
+    // MFMA j (0..5) of d step kg.  The first MFMA of a chain starts from C = -reference (biased: the scores come out
+    // as s - reference, ready for v_exp) or from the inline constant 0 (raw scores): no fill instructions either way
+    auto qk_step = [&](int kg, int j, const KFrag& f, f32x16& d0, f32x16& d1, auto biased) {
+        const f32x16 zero = {};
+        const f32x16 c_init = decltype(biased)::value ? nref : zero;
+        if (j == 0) d0 = mfma_f16(f.k0l, qh[kg], kg == 0 ? c_init : d0);
+        if (j == 1) d1 = mfma_f16(f.k1l, qh[kg], kg == 0 ? c_init : d1);
         if (j == 2) d0 = mfma_f16(f.k0h, ql[kg], d0);
         if (j == 3) d1 = mfma_f16(f.k1h, ql[kg], d1);
         if (j == 4) d0 = mfma_f16(f.k0h, qh[kg], d0);
@@ -453,20 +459,23 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
             if (key + 32 >= N) d1[i] = -INFINITY;
         }
     };
-    // Online softmax of (c0, c1) with a LAZY reference (log2 domain): p' = 2^(s - m_ref + 8), where m_ref is the row
-    // maximum as of the last exact pass, not of this tile.  On gfx950 every VALU instruction issued between the MFMAs
-    // takes about two cycles from the matrix pipe (DESIGN.md finding 4), so the per-tile row maximum (16 v_max3, the
-    // swap across the two 32-lane halves, its wait states) and the unconditional rescale of o and l (21 multiplies)
-    // are the part of the softmax that can go: a tile whose scores stay below m_ref + 8 needs neither — p' < 2^16
-    // still splits into f16 (hi, lo), and with at least 2^8 of headroom under the running maximum the split keeps
-    // fp32 accuracy.  The tile's probability sum (computed anyway) tells: any p' >= 65 504 makes it >= 65 504.  Only
-    // then — and for NaN/inf — `redo_tile` recomputes the tile's scores from its K stage (still resident) and takes
-    // the exact pass: true row maximum, rescale, new m_ref.  Results never depend on which path ran beyond fp32
+    // Online softmax of (c0, c1) with a LAZY reference (log2 domain): p' = 2^(s - ref), where ref = (the row maximum
+    // as of the last exact pass) - 8, not this tile's.  On gfx950 every VALU instruction issued between the MFMAs takes
+    // about two cycles from the matrix pipe (DESIGN.md finding 4), so what can go, goes:
+    //   * the per-tile row maximum (16 v_max3, the swap across the two 32-lane halves, its wait states) and the
+    //     unconditional rescale of o and l (21 multiplies): a tile whose scores stay below ref + 16 needs neither —
+    //     p' < 2^16 still splits into f16 (hi, lo), and with 2^8 of headroom under the running maximum the split keeps
+    //     fp32 accuracy;
+    //   * the subtraction: the score MFMAs start from C = -ref (nref), so s - ref is what they deliver.
+    // The tile's probability sum (computed anyway) tells whether that held: any p' >= 65 504 makes it >= 65 504.  Only
+    // then — and for NaN/inf — `redo_tile` recomputes the tile's raw scores from its K stage (still resident) and
+    // takes the exact pass: true row maximum, new reference, o and l rescaled, and the next tile's scores (already
+    // computed against the old reference) shifted to the new one.  Results do not depend on which path ran beyond fp32
     // rounding; the speed does (diffuse attention rows: exact pass on tile 0 only).
     constexpr float LAZY_HEADROOM = 8.0f, LAZY_LIMIT = 65504.0f;
-    float sm_shift = 0.f;
     f32x2 sm_ls = {0.f, 0.f};
-    auto exact_prepare = [&](const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {  // true row maximum of the raw scores -> m_run; o, l rescaled
+    // true row maximum of the RAW scores (c0, c1) -> new reference; o and l rescaled; returns old - new reference
+    auto exact_prepare = [&](const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {
         float mt = vmax3(c0[0], c1[0], c0[1]);
 #pragma unroll
         for (int i = 1; i < 15; ++i) mt = vmax3(mt, c1[i], c0[i + 1]);
@@ -477,33 +486,44 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         // not look into inline asm, and VALU write -> permlane swap -> VALU read need wait states on gfx950.
         float ma, mb;
         pope_xor32_pair(mt, ma, mb);
-        const float m_new = __builtin_fmaxf(m_run, __builtin_fmaxf(ma, mb));
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: 2^(-inf) = 0 on o = l = 0
-        m_run = m_new;
-        sm_shift = m_new - LAZY_HEADROOM;
+        const float ref_old = -nref[0];
+        const float ref_new = __builtin_fmaxf(ref_old, __builtin_fmaxf(ma, mb) - LAZY_HEADROOM);  // never decreases
+        const float delta = ref_old - ref_new;                 // first tile: -inf
+        const float alpha = __builtin_amdgcn_exp2f(delta);     // first tile: 0 on o = l = 0
+#pragma unroll
+        for (int i = 0; i < 16; ++i) nref[i] = -ref_new;
         l_run = l_run * alpha;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+        return delta;
     };
-    auto exp_pair = [&](int i, f32x16& c0, f32x16& c1) __attribute__((always_inline)) {
-        // in place, and the two of a packed add adjacent in their tuple: pairing c0[i] with c1[i] makes the register
-        // allocator permute the tuples for the v_pk_add and copy them back (24 v_mov per tile)
+    // two probabilities, in place, adjacent in their tuple (pairing c0[i] with c1[i] makes the register allocator
+    // permute the tuples for the v_pk_add and copy them back: 24 v_mov per tile); biased: the scores are s - ref already
+    auto exp_pair = [&](int i, f32x16& c0, f32x16& c1, auto biased) __attribute__((always_inline)) {
         f32x16& c = i < 8 ? c0 : c1;
         const int e = 2 * (i & 7);
-        c[e] = __builtin_amdgcn_exp2f(c[e] - sm_shift);
-        c[e + 1] = __builtin_amdgcn_exp2f(c[e + 1] - sm_shift);
+        if constexpr (decltype(biased)::value) {
+            c[e] = __builtin_amdgcn_exp2f(c[e]);
+            c[e + 1] = __builtin_amdgcn_exp2f(c[e + 1]);
+        } else {
+            c[e] = __builtin_amdgcn_exp2f(c[e] + nref[0]);
+            c[e + 1] = __builtin_amdgcn_exp2f(c[e + 1] + nref[0]);
+        }
         sm_ls += f32x2{c[e], c[e + 1]};
         // pin the running sum to its slot: the optimiser otherwise sinks the whole (dependent) chain of adds out of
         // the MFMA shadow to the top of the next iteration, right behind the barrier, one s_nop per add
         asm volatile("" : "+v"(sm_ls));
     };
-    // slice `slot` (0..23) of the fast pass: two probabilities of each sub-tile in two of every three slots
-    auto softmax_slice = [&](int slot, auto ptag) {
+    // slice `slot` (0..23) of the fast pass: two probabilities behind two of every three MFMAs.  (Measured and dropped:
+    // four pairs in front of the first MFMA, under the latency of its K fragments; 2, 3 or 6 pairs behind every 4th,
+    // 6th or 12th MFMA; both halves of a P split behind one MFMA — all 0.5 to 2 % slower than the even spread.)
+    auto softmax_slice = [&](int slot, auto ptag) __attribute__((always_inline)) {
 #ifdef ATTN_ABL_NOSOFTMAX  // dev ablation (wrong results): what the phase costs without its VALU work
         return;
 #endif
         if (slot == 0) sm_ls = f32x2{0.f, 0.f};
-        if (slot % 3 != 2) exp_pair((slot / 3) * 2 + slot % 3, sb[decltype(ptag)::value][0], sb[decltype(ptag)::value][1]);
+        if (slot % 3 != 2)
+            exp_pair((slot / 3) * 2 + slot % 3, sb[decltype(ptag)::value][0], sb[decltype(ptag)::value][1], std::true_type{});
     };
     // the exact pass for tile `tile` (its K rows in stage st): scores again, true maximum, rescale, probabilities
     auto redo_tile = [&](int tile, int st, auto ptag) __attribute__((always_inline)) {
@@ -515,7 +535,7 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         for (int kg = 0; kg < 4; ++kg) {
             read_kfrag(st, kg, kf);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) qk_step(kg, j, kf, d0, d1);
+            for (int j = 0; j < 6; ++j) qk_step(kg, j, kf, d0, d1, std::false_type{});
         }
         if ((tile + 1) * KT > N) mask_tail(tile, d0, d1);
         // hand the scores back IN the registers the fast pass uses ("+v" ties them): a plain assignment makes the
@@ -527,10 +547,15 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
             asm volatile("v_mov_b32 %0, %1" : "+v"(c0[i]) : "v"(d0[i]));
             asm volatile("v_mov_b32 %0, %1" : "+v"(c1[i]) : "v"(d1[i]));
         }
-        exact_prepare(c0, c1);
+        const float delta = exact_prepare(c0, c1);
         sm_ls = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) exp_pair(i, c0, c1);
+        for (int i = 0; i < 16; ++i) exp_pair(i, c0, c1, std::false_type{});
+        // the next tile's scores were computed against the old reference (garbage after the last tile: harmless)
+        f32x16& n0 = sb[decltype(ptag)::value ^ 1][0];
+        f32x16& n1 = sb[decltype(ptag)::value ^ 1][1];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { n0[i] += delta; n1[i] += delta; }
     };
     // after the fast pass of a tile: did every probability fit?  (wave-uniform branch; !(x < limit) also catches NaN)
     auto settle = [&](int tile, int st, auto ptag) __attribute__((always_inline)) {
@@ -551,7 +576,7 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         for (int i = 0; i < 24; ++i) {
             const int kg = i / 6, j = i % 6;
             if (j == 0 && kg < 3) read_kfrag(st_next, kg + 1, kf[(kg + 1) & 1]);
-            qk_step(kg, j, kf[kg & 1], n0, n1);
+            qk_step(kg, j, kf[kg & 1], n0, n1, std::true_type{});
             softmax_slice(i, ptag);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -638,7 +663,7 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         for (int kg = 0; kg < 4; ++kg) {
             read_kfrag(0, kg, kf);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) qk_step(kg, j, kf, sb[0][0], sb[0][1]);
+            for (int j = 0; j < 6; ++j) qk_step(kg, j, kf, sb[0][0], sb[0][1], std::false_type{});
         }
     }
     if (nkt == 1) mask_tail(0, sb[0][0], sb[0][1]);
@@ -653,7 +678,9 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     }
     __syncthreads();
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sb[0][0]), "+v"(sb[0][1]));  // XDL write -> asm VALU read (vmax3) wait states
-    exact_prepare(sb[0][0], sb[0][1]);  // tile 0 sets the first reference
+    exact_prepare(sb[0][0], sb[0][1]);  // tile 0 sets the first reference; its raw scores are shifted here, once
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sb[0][0][i] += nref[0]; sb[0][1][i] += nref[0]; }
 
     // stage of tile t = t % 3
     int st_cur = 0, st_next = 1, st_write = 2, t = 0;
