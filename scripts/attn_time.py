@@ -6,6 +6,14 @@ dev = torch.device("cuda:0")
 B, N, H = 64, 1531, 6
 g = torch.Generator(device=dev).manual_seed(0)
 qkv = torch.randn(B, N, 3 * H * 64, device=dev, generator=g)
+if len(sys.argv) > 1:  # "ramp <step>": scores climbing by <step> per 64-key tile (drives the exact pass of the lazy softmax)
+    step = float(sys.argv[2])
+    t = qkv.view(B, N, 3, H, 64)
+    t.mul_(0.3)
+    u = torch.randn(H, 64, device=dev, generator=g)
+    u = u / u.norm(dim=-1, keepdim=True) * 8.0
+    t[:, :, 0] += u
+    t[:, :, 1] += u * (torch.arange(N, device=dev, dtype=torch.float32) / 64.0 * (step / 8.0))[None, :, None, None]
 lib = C.CDLL(_lib.LIB_PATH)
 pin = _lib.to_planes(qkv.reshape(B * N, -1).cpu(), 8.0).to(dev)
 pout = torch.zeros(B * N, H * 2, 2, 32, dtype=torch.float16, device=dev)
