@@ -732,23 +732,28 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     else tail(P0{});
     __syncthreads();  // the stages are free: reuse them for the O^T transpose
 
-    // Normalise (the 2^10 of p' cancels), transpose O^T through LDS, store whole 256-B head rows.
+    // Normalise (the 2^8 of p' cancels), transpose O^T through LDS, store whole 256-B head rows.  The lane coordinates
+    // are derived again from threadIdx behind an asm fence: kept live across the main loop they are what gets spilled
+    // (the loop runs at 256 VGPRs) — a scratch round trip per thread for four registers.
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wave_e = tid_e >> 6, r_e = lane_e & 31, h_e = lane_e >> 5;
     const float l_half = l_run[0] + l_run[1];
     const float inv = (IN_PLANES ? 0.125f : 1.0f) / (l_half + __shfl_xor(l_half, 32));  // V planes carry x8
-    float* Os = smem + (wave * 32) * OST;
+    float* Os = smem + (wave_e * 32) * OST;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
         f32x4 a, c;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { a[e] = o0[4 * g4 + e] * inv; c[e] = o1[4 * g4 + e] * inv; }
-        *reinterpret_cast<f32x4*>(&Os[r * OST + 8 * g4 + 4 * h]) = a;
-        *reinterpret_cast<f32x4*>(&Os[r * OST + 32 + 8 * g4 + 4 * h]) = c;
+        *reinterpret_cast<f32x4*>(&Os[r_e * OST + 8 * g4 + 4 * h_e]) = a;
+        *reinterpret_cast<f32x4*>(&Os[r_e * OST + 32 + 8 * g4 + 4 * h_e]) = c;
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int lr = (lane >> 4) + 4 * i, c4 = (lane & 15) * 4;
-        const int qrow = q0 + wave * 32 + lr;
+        const int lr = (lane_e >> 4) + 4 * i, c4 = (lane_e & 15) * 4;
+        const int qrow = q0 + wave_e * 32 + lr;
         const f32x4 v = *reinterpret_cast<const f32x4*>(&Os[lr * OST + c4]);
         if (qrow < N) {
             if constexpr (OUT_PLANES) {
