@@ -46,9 +46,10 @@ enum {
 /* Arithmetic of the contractions.  Both take and return fp32 and accumulate in fp32:
  *  POPE_PREC_F32_MFMA  v_mfma_f32_32x32x2_f32, an exact k-ordered fp32 fma chain (157 TFLOP/s peak; on gfx950
  *                      this instruction runs on the VALU lanes);
- *  POPE_PREC_F16X3     operands split x = hi + lo (two f16, 22 significand bits), three
- *                      v_mfma_f32_32x32x16_f16 per product block on the matrix cores: same or smaller error
- *                      than the fp32 chain for |x| < 65504 (measured against fp64), 2.4x+ faster. */
+ *  POPE_PREC_F16X3     operands split x = hi + lo (two f16, 22 significand bits), three f16 MFMAs
+ *                      (v_mfma_f32_16x16x32_f16 in the GEMMs, v_mfma_f32_32x32x16_f16 in attention) per product
+ *                      block on the matrix cores: same or smaller error than the fp32 chain inside the range
+ *                      contract below (measured against fp64), 2.3x faster end to end. */
 enum { POPE_PREC_F32_MFMA = 0, POPE_PREC_F16X3 = 1 };
 /* bits of a range_flag word: which f16x3 producer saw a value out of range */
 enum { POPE_RANGE_PATCH = 1, POPE_RANGE_LAYERNORM = 2, POPE_RANGE_QKV = 4, POPE_RANGE_GELU = 8, POPE_RANGE_MATCH = 16,
