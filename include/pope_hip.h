@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define POPE_ABI_VERSION 4
+#define POPE_ABI_VERSION 5
 
 enum {
     POPE_EPI_BIAS = 0,        /* C = A.W^T + bias                         nn.Linear                     */
@@ -231,6 +231,27 @@ size_t pope_loftr_layer_workspace_bytes(int n, int L, int S, int C, int nhead);
 int pope_loftr_encoder_layer_f32(const pope_loftr_layer_weights* w_host, float* x, const float* source,
                                  int n, int L, int S, int C, int nhead, float ln_eps,
                                  void* workspace, size_t workspace_bytes, unsigned* range_flag, void* stream);
+
+/* ResNetFPN_8_2.forward — src/matcher/backbone/resnet_fpn.py:100-118 (BasicBlock :15-40), eval mode: the LoFTR
+ * matcher's local-feature CNN.  gray[n,1,H,W] in [0,1], H and W multiples of 8.  Every convolution is an f16x3 planes
+ * GEMM over zero-bordered NHWC activations (3x3 stride 1: implicit, no im2col; pope_amd/csrc/conv.hip); eval-mode
+ * BatchNorm is folded into filter and bias by the caller.  Weights: planes (pope_split_planes_f32, scale 256) of
+ * [Cout, K] matrices with K = taps x input channels rounded up to 32 (zero filled), tap-major (ky, kx, c):
+ *   0 conv1+bn1 (K = 64: the 49 taps of the 7x7)            1..4  layer1: b0.conv1, b0.conv2, b1.conv1, b1.conv2
+ *   5..9  layer2: b0.conv1, b0.conv2, b0.downsample (1x1), b1.conv1, b1.conv2        10..14 layer3: the same
+ *   15 layer3_outconv  16 layer2_outconv  17 layer2_outconv2[0]+bn  18 layer2_outconv2[3]
+ *   19 layer1_outconv  20 layer1_outconv2[0]+bn  21 layer1_outconv2[3]
+ * b[i] = folded bias [Cout] or NULL (15, 16, 18, 19, 21).  Channel widths 128 / 196 / 256 (cvpr_ds_config.py).
+ * Outputs are NHWC with a one-pixel border: out_c[n, H/8+2, W/8+2, 256] (x3_out; border zero) and
+ * out_f[n, H/2+2, W/2+2, 128] (x1_out; border undefined) — the reference's NCHW maps are the interiors, permuted. */
+typedef struct pope_resnetfpn_weights {
+    const void* w[22];
+    const float* b[22];
+} pope_resnetfpn_weights;
+size_t pope_resnetfpn_workspace_bytes(int n, int H, int W);
+int pope_resnetfpn_forward_f32(const pope_resnetfpn_weights* w_host, const float* gray, int n, int H, int W,
+                               float* out_c, float* out_f, void* workspace, size_t workspace_bytes,
+                               unsigned* range_flag, void* stream);
 
 /* ---- caller-side preprocessing, batched ------------------------------------------------- */
 

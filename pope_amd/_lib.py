@@ -34,6 +34,10 @@ class LoftrLayerWeights(C.Structure):
                                            "norm2_b")]
 
 
+class ResnetFpnWeights(C.Structure):
+    _fields_ = [("w", C.c_void_p * 22), ("b", C.c_void_p * 22)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/pope_hip.h
 PREC_F32_MFMA, PREC_F16X3 = 0, 1
 PLANES_ACT_SCALE, PLANES_W_SCALE = 8.0, 256.0
@@ -82,6 +86,9 @@ PROTOTYPES = {
     "pope_loftr_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "pope_loftr_encoder_layer_f32": (C.c_int, [C.POINTER(LoftrLayerWeights), C.c_void_p, C.c_void_p] + [C.c_int] * 5
                                      + [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "pope_resnetfpn_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "pope_resnetfpn_forward_f32": (C.c_int, [C.POINTER(ResnetFpnWeights), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pope_preprocess_u8_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3
                                + [C.c_int] * 7 + [c_float_p, c_float_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pope_gray_u8_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -123,7 +130,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.pope_abi_version() != 4:
+        if handle.pope_abi_version() != 5:
             raise RuntimeError("libpope_hip.so ABI version mismatch")
         _lib = handle
     return _lib

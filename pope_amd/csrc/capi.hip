@@ -514,6 +514,22 @@ int pope_loftr_encoder_layer_f32(const pope_loftr_layer_weights* w, float* x, co
     return pope_launch_loftr_layer(p, static_cast<hipStream_t>(stream));
 }
 
+size_t pope_resnetfpn_workspace_bytes(int n, int H, int W) {
+    if (n <= 0 || H < 16 || W < 16 || (H & 7) || (W & 7)) return 0;
+    return pope_resnetfpn_workspace(n, H, W);
+}
+
+int pope_resnetfpn_forward_f32(const pope_resnetfpn_weights* w, const float* gray, int n, int H, int W, float* out_c, float* out_f,
+                               void* workspace, size_t workspace_bytes, unsigned* range_flag, void* stream) {
+    StreamDevice on_device(stream);
+    if (!w) return POPE_ERR_ARG;
+    ResnetFpnParams q = {};
+    q.img = gray; q.n = n; q.H = H; q.W = W;
+    for (int i = 0; i < 22; ++i) { q.w[i] = w->w[i]; q.b[i] = w->b[i]; }
+    q.out_c = out_c; q.out_f = out_f; q.ws = workspace; q.ws_bytes = workspace_bytes; q.range_flag = range_flag;
+    return pope_launch_resnetfpn(q, static_cast<hipStream_t>(stream));
+}
+
 int pope_preprocess_u8_f32(const unsigned char* img_hwc, int P, int Hin, int Win, const int* hstart, const int* hcount,
                            const int* hk, int kh, const int* vstart, const int* vcount, const int* vk, int kv, int top, int left,
                            int ch, int cw, int row0, int nrows, const float* mean_host, const float* std_host, float* out,

@@ -57,7 +57,7 @@ __device__ __forceinline__ f32x2 gelu_erf_pair(f32x2 x) {
     return __builtin_elementwise_fma(relu, __builtin_elementwise_fma(q, f32x2{-2.f, -2.f}, f32x2{1.f, 1.f}), x * q);
 }
 
-template <int EPI, bool OUT_PLANES>
+template <int EPI, bool OUT_PLANES, bool CONV = false>
 __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmParams g, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* lds = reinterpret_cast<_Float16*>(smem);
@@ -73,8 +73,13 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
     const int prow = tid >> 3, pc = tid & 7;
     const int nk = g.K / BK;  // >= 2 (launcher)
     const unsigned nb = EPI == EPI_SIM ? unsigned(g.nbatch) : 1u;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, nb * unsigned(g.M) * unsigned(g.lda) * 4u, 0x00020000);
+    const unsigned a_rows = CONV ? unsigned(g.M) + 2u * unsigned(g.conv_wp) + 2u : nb * unsigned(g.M);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, a_rows * unsigned(g.lda) * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, nb * unsigned(g.N) * unsigned(g.ldw) * 4u, 0x00020000);
+    // CONV: byte offset of the next K-step's A rows = (dy * Wp + dx) rows + chunk * 128, kept incrementally (scalar
+    // selects: the K-step stays one basic block)
+    const int cv_row = g.lda * 4, cv_dy = (g.conv_wp - 2) * cv_row;
+    int cv_chunk = 0, cv_dx = 0, cv_off = 0;
 
     // Tile stream of this persistent workgroup (gemm_f16x3.hip has the measurements behind every choice here): full
     // rounds by XCD-remapped id, the partial last round one tile per CU by raw blockIdx; the K-steps of consecutive
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned va = unsigned(m0 + prow + 32 * i) * unsigned(g.lda) * 4u + pc * 16u;
-            st[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, ld_kt * 128, 0);
+            st[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, CONV ? cv_off + cv_chunk * 128 : ld_kt * 128, 0);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -116,6 +121,14 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
             st[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, ld_kt * 128, 0);
         }
         const int wrap = ++ld_kt == nk;
+        if constexpr (CONV) {
+            const int cwrap = ++cv_chunk == g.conv_cch;                  // next tap
+            cv_chunk = pope_uniform_select(cwrap, 0, cv_chunk);
+            const int xwrap = cwrap & (cv_dx == 2);                       // next tap row
+            cv_off += pope_uniform_select(cwrap, pope_uniform_select(xwrap, cv_dy, cv_row), 0);
+            cv_dx = pope_uniform_select(cwrap, pope_uniform_select(xwrap, 0, cv_dx + 1), cv_dx);
+            cv_off = pope_uniform_select(wrap, 0, cv_off);                // next tile: tap (0, 0) again
+        }
         ld_kt = pope_uniform_select(wrap, 0, ld_kt);
         ld_ord += wrap;
         ld_tile = tile_of(ld_ord);
@@ -145,6 +158,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
         const_cast<float*>(EPI == EPI_BIAS_LS_RES ? g.res : g.C), 0,
         EPI == EPI_BIAS_LS_RES ? unsigned(g.res_mod > 0 ? g.res_mod : g.M) * unsigned(g.ldres) * 4u : 0u, 0x00020000);
     auto res_row = [&](unsigned row) -> unsigned { return g.res_mod > 0 ? row % unsigned(g.res_mod) : row; };
+    const __amdgpu_buffer_rsrc_t rresp = __builtin_amdgcn_make_buffer_rsrc(   // EPI_CONV: residual as activation planes
+        const_cast<void*>(EPI == EPI_CONV ? g.res_pl : nullptr), 0,
+        EPI == EPI_CONV && g.res_pl ? unsigned(g.M) * unsigned(g.ldres_pl) * 4u : 0u, 0x00020000);
     const int ec4 = (lane & 15) * 4, elr = lane >> 4;   // row-layout coordinates after the LDS transposition
     constexpr unsigned DROP = 0xFFFFFF00u;              // beyond every buffer extent: the access is discarded
 
@@ -322,6 +338,16 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
                     res[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                  rres, col_ok ? res_row(row0 + 4 * i) * unsigned(g.ldres) * 4u + unsigned(col) * 4u : DROP, 0, 0));
             }
+            if constexpr (EPI == EPI_CONV) {   // shortcut rows: (hi + lo) / 8; an empty descriptor (no residual) reads zeros
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned o = (row0 + 4 * i) * unsigned(g.ldres_pl) * 4u + unsigned((col >> 5) * 128 + (col & 31) * 2);
+                    const f16x4 rh = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rresp, col_ok ? o : DROP, 0, 0));
+                    const f16x4 rl = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rresp, col_ok ? o + 64u : DROP, 0, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) res[i][e] = (float(rh[e]) + float(rl[e])) * (1.0f / A_SCALE);
+                }
+            }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -337,6 +363,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
                     v = v * inv + bias;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(v[e], 0.f);
+                } else if constexpr (EPI == EPI_CONV) {
+                    v = (v * inv + bias) + res[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(v[e], 0.f) + g.act_slope * __builtin_fminf(v[e], 0.f);
                 } else {
                     v = res[i] + v * gamma + bias;
                 }
@@ -428,13 +458,13 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
     }
 }
 
-template <int EPI, bool OUT_PLANES>
+template <int EPI, bool OUT_PLANES, bool CONV = false>
 int launch16(const GemmParams& g, hipStream_t stream, int nbatch = 1) {
     static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
-    if (!pope_opt_in_lds(gemm_planes16_kernel<EPI, OUT_PLANES>, P16_LDS_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
+    if (!pope_opt_in_lds(gemm_planes16_kernel<EPI, OUT_PLANES, CONV>, P16_LDS_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
     const int tiles = nbatch * ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     const int slots = 2 * pope_cu_count();   // two resident workgroups per CU (2 x 80 KB LDS)
-    hipLaunchKernelGGL((gemm_planes16_kernel<EPI, OUT_PLANES>), dim3(tiles < slots ? tiles : slots), dim3(THREADS), P16_LDS_BYTES,
+    hipLaunchKernelGGL((gemm_planes16_kernel<EPI, OUT_PLANES, CONV>), dim3(tiles < slots ? tiles : slots), dim3(THREADS), P16_LDS_BYTES,
                        stream, g, tiles);
     return pope_check_launch();
 }
@@ -450,6 +480,12 @@ int pope_launch_planes16(const GemmParams& g, hipStream_t stream) {
         case EPI_BIAS_RELU: return out_planes ? launch16<EPI_BIAS_RELU, true>(g, stream) : launch16<EPI_BIAS_RELU, false>(g, stream);
         case EPI_BIAS_LS_RES: return launch16<EPI_BIAS_LS_RES, false>(g, stream);
         case EPI_SIM: return launch16<EPI_SIM, false>(g, stream, g.nbatch);
+        case EPI_CONV:
+            if (g.conv_cch > 0) {
+                if (g.K != 9 * 32 * g.conv_cch || g.lda != 32 * g.conv_cch || g.conv_wp < 3) return POPE_ERR_ARG;
+                return out_planes ? launch16<EPI_CONV, true, true>(g, stream) : launch16<EPI_CONV, false, true>(g, stream);
+            }
+            return out_planes ? launch16<EPI_CONV, true>(g, stream) : launch16<EPI_CONV, false>(g, stream);
     }
     return POPE_ERR_ARG;
 }

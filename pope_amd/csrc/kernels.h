@@ -11,6 +11,8 @@ enum GemmEpilogue {
     EPI_POSB = 3,         // patch embed: C = im2col(img).W^T + posb[token]   (A = image)
     EPI_BIAS_RELU = 5,    // C = max(A.W^T + bias, 0)                (LoFTR encoder MLP, transformer.py:24-28; gemm_planes.hip only)
     EPI_SIM = 4,          // batched similarity (planes kernel): C[b] = (A[b].W[b]^T * alpha) / divisor, no bias
+    EPI_CONV = 6,         // C = act(A.W^T + bias [+ res_pl]), act(v) = max(v, 0) + act_slope * min(v, 0): ReLU (0), LeakyReLU
+                          // (0.01) or identity (1); the ResNet-FPN convolutions (conv.hip; gemm_planes.hip only)
 };
 
 struct GemmParams {
@@ -58,6 +60,16 @@ struct GemmParams {
     float ln_eps;
     void* ln_planes;
     float* ln_f32;
+    // EPI_CONV (gemm_planes.hip): optional residual as activation planes [M, ldres_pl] (BasicBlock shortcut), activation
+    // slope, and — conv_cch > 0 — the implicit 3x3 stride-1 convolution over a zero-bordered NHWC planes tensor
+    // [n, Hp, Wp = conv_wp, 32 * conv_cch channels]: output row R = pixel R + Wp + 1, and the A row of K-step
+    // (tap (dy, dx), chunk c) is row R + dy * Wp + dx, chunk c — a row-uniform shift, i.e. a scalar offset per K-step
+    // (K = 9 * 32 * conv_cch; W rows hold the taps in (dy, dx, channel) order); a_pl may be read up to 2 Wp + 2 rows
+    // past M (the caller's buffer has them, or the range check returns zeros)
+    const void* res_pl;
+    int ldres_pl;
+    float act_slope;
+    int conv_cch, conv_wp;
     // patch-embed gather (EPI_POSB)
     const float* posb;   // [ntok, N]: row 0 = cls_token + pos[0]; row n = conv bias + pos[n]
     int ntok, img_h, img_w, patch, grid_w;
@@ -167,5 +179,18 @@ struct LoftrLayerParams {
     void* ws; size_t ws_bytes;
     unsigned* range_flag;
 };
+// ResNet-FPN local-feature CNN of the LoFTR matcher (conv.hip; resnet_fpn.py:43-118)
+struct ResnetFpnParams {
+    const float* img;          // [n, 1, H, W] gray in [0, 1]
+    int n, H, W;               // H, W multiples of 8
+    const void* w[22];         // weight planes (scale 256), BatchNorm folded: order in pope_hip.h
+    const float* b[22];        // folded biases (null where the reference has neither bias nor BatchNorm)
+    float* out_c;              // [n, H/8 + 2, W/8 + 2, 256] fp32, zero border
+    float* out_f;              // [n, H/2 + 2, W/2 + 2, 128] fp32, border undefined
+    void* ws; size_t ws_bytes;
+    unsigned* range_flag;
+};
+size_t pope_resnetfpn_workspace(int n, int H, int W);
+int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream);
 size_t pope_loftr_layer_workspace(int n, int L, int S, int C, int H);
 int pope_launch_loftr_layer(const LoftrLayerParams& p, hipStream_t stream);

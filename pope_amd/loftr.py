@@ -78,6 +78,8 @@ class ResNetFPN_8_2(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
         self._folded = None
+        self._hip = None
+        self.use_hip = True   # dev / test switch: False = the torch / MIOpen form on any device
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     def _fold(self):
@@ -91,10 +93,79 @@ class ResNetFPN_8_2(nn.Module):
 
     def invalidate(self):
         self._folded = None
+        self._hip = None
 
     def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float() move the parameters: refold lazily
         self._folded = None
+        self._hip = None
         return super()._apply(fn, *a, **k)
+
+    def _hip_weights(self):
+        """The 22 convolutions as f16x3 weight planes in the order of pope_hip.h (BatchNorm folded, [Cout, taps x Cin
+        rounded up to 32] tap-major), biases as fp32.  None when a folded filter leaves the f16x3 weight range."""
+        from . import _lib
+        if self._hip is not None:
+            return self._hip[0]
+        f = self._folded
+
+        def mat(w):   # [Cout, Cin, kh, kw] -> [Cout, kh * kw * Cp]
+            co, ci, kh, kw = w.shape
+            if ci == 1:   # the 7x7 stem: 49 taps of one channel, zero-filled to 64 columns
+                m = w.reshape(co, kh * kw)
+                return F.pad(m, (0, 64 - kh * kw))
+            cp = (ci + 31) // 32 * 32
+            return F.pad(w.permute(0, 2, 3, 1), (0, cp - ci)).reshape(co, kh * kw * cp)
+
+        convs = [f["stem"]]
+        for lf in f["blocks"]:
+            for bf in lf:
+                convs += bf                      # conv1, conv2[, downsample]
+        # reorder layer2 / layer3 entries to conv1, conv2, downsample, conv1, conv2 (already so: b0 has 3, b1 has 2)
+        convs += [(self.layer3_outconv.weight, None), (self.layer2_outconv.weight, None), f["out2"],
+                  (self.layer2_outconv2[3].weight, None), (self.layer1_outconv.weight, None), f["out1"],
+                  (self.layer1_outconv2[3].weight, None)]
+        assert len(convs) == 22
+        mats = [mat(w.detach().float()).contiguous() for w, _ in convs]
+        amax = max(float(m.abs().max()) for m in mats)
+        if not amax * _lib.PLANES_W_SCALE < _lib.F16_MAX:
+            self._hip = (None, None)
+            return None
+        keep = [_lib.to_planes(m, _lib.PLANES_W_SCALE) for m in mats]
+        biases = [None if b is None else b.detach().float().contiguous() for _, b in convs]
+        st = _lib.ResnetFpnWeights()
+        for i in range(22):
+            st.w[i] = keep[i].data_ptr()
+            st.b[i] = None if biases[i] is None else biases[i].data_ptr()
+        self._hip = (st, keep + [b for b in biases if b is not None])
+        return st
+
+    def _forward_hip(self, x):
+        """One C-ABI call (pope_resnetfpn_forward_f32, conv.hip): every convolution on the f16x3 planes GEMM.  Returns the
+        reference's NCHW maps as views of the zero-bordered NHWC outputs, or None when the f16x3 range guard fired."""
+        import ctypes as C
+        from . import _lib
+        w = self._hip_weights()
+        if w is None:
+            return None
+        n, _, H, W = x.shape
+        x = x.float().contiguous()
+        dev = x.device
+        out_c = torch.empty(n, H // 8 + 2, W // 8 + 2, 256, dtype=torch.float32, device=dev)
+        out_f = torch.empty(n, H // 2 + 2, W // 2 + 2, 128, dtype=torch.float32, device=dev)
+        nbytes = _lib.lib().pope_resnetfpn_workspace_bytes(n, H, W)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        with _lib.on_device_of(x):
+            _lib.check(_lib.lib().pope_resnetfpn_forward_f32(
+                C.byref(w), C.c_void_p(x.data_ptr()), n, H, W, C.c_void_p(out_c.data_ptr()), C.c_void_p(out_f.data_ptr()),
+                C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(flag.data_ptr()), _lib.stream_of(dev)), "pope_resnetfpn_forward_f32")
+        bits = int(flag.item())
+        if bits:
+            import warnings
+            warnings.warn(f"pope_amd: f16x3 range contract breached in the LoFTR backbone ({_lib.describe_range_bits(bits)}); "
+                          "re-running it in torch fp32")
+            return None
+        return [out_c[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2), out_f[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)]
 
     @torch.no_grad()
     def forward(self, x):
@@ -103,6 +174,11 @@ class ResNetFPN_8_2(nn.Module):
         if self._folded is None:
             self._folded = self._fold()
         f = self._folded
+        if self.use_hip and x.is_cuda and x.shape[0] > 0 and x.shape[1] == 1 and x.shape[2] % 8 == 0 and x.shape[3] % 8 == 0 \
+                and x.shape[2] >= 16 and x.shape[3] >= 16:
+            out = self._forward_hip(x)
+            if out is not None:
+                return out
         x0 = F.relu_(F.conv2d(x, f["stem"][0], f["stem"][1], 2, 3))
         feats = []
         h = x0

@@ -80,9 +80,12 @@ def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, tempera
     counts = torch.zeros(n + 2, dtype=torch.int32, device=dev)   # per-pair counts | total | f16x3 range-guard word
     flag_ptr = C.c_void_p(counts.data_ptr() + 4 * (n + 1)) if precision == "f16x3" else None
     scale = hw0_i[0] / hw0_c[0]  # coarse_matching.py:242 (heights only)
+    # (the stride of a size-1 dimension is arbitrary in torch: a batch of one has no batch stride to speak of)
+    bs0 = feat0.stride(0) if n > 1 else L * Cc
+    bs1 = feat1.stride(0) if n > 1 else S * Cc
     with on_device_of(feat0):
-        check(lib.pope_dense_match_prec_f32(C.c_void_p(feat0.data_ptr()), feat0.stride(0), C.c_void_p(feat1.data_ptr()),
-                                            feat1.stride(0), n, L, S, Cc, h0, w0, h1, w1, float(thr), int(border_rm),
+        check(lib.pope_dense_match_prec_f32(C.c_void_p(feat0.data_ptr()), bs0, C.c_void_p(feat1.data_ptr()),
+                                            bs1, n, L, S, Cc, h0, w0, h1, w1, float(thr), int(border_rm),
                                             float(temperature), float(scale), ptr(conf), ptr(b_ids), ptr(i_ids), ptr(j_ids),
                                             ptr(mconf), ptr(mk0), ptr(mk1), ptr(counts), C.c_void_p(ws.data_ptr()), ws_bytes,
                                             prec, flag_ptr, stream_of(dev)), "pope_dense_match_prec_f32")

@@ -17,6 +17,16 @@ for n in (3, 24):
     for _ in range(10): d = {"image0": a, "image1": b}; m(d)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
     print(f"Matcher batch {n} x 256x256: {dt*1e3:.2f} ms per call = {n/dt:.0f} LoFTR pairs/s, {len(d['b_ids'])} matches")
+for n in (6, 48):   # the CNN alone: HIP planes-GEMM convolutions against the torch / MIOpen form
+    x = torch.cat([i0, i1], 0).repeat(n // 6, 1, 1, 1)
+    for hip in (True, False):
+        m.backbone.use_hip = hip
+        for _ in range(3): m.backbone(x)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): m.backbone(x)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+        print(f"backbone {n} x 256x256 ({'HIP' if hip else 'MIOpen'}): {dt*1e3:.2f} ms = {n * 63.1 / dt / 1e3:.1f} TFLOP/s")
+m.backbone.use_hip = True
 case = [t.to(dev) for t in synth.synthetic_driver_case()]
 for _ in range(3): locate_and_match(vit, m, *case)
 torch.cuda.synchronize(); t0 = time.perf_counter()
