@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void upsample_add_planes_kernel(const float* _
                                                                   int lds, _Float16* __restrict__ out, int Cp, int C, int n, int Hp,
                                                                   int Wp, unsigned* range_flag) {
     const int H = Hp - 2, W = Wp - 2, Hs = H / 2, Ws = W / 2, Hsp = Hs + 2, Wsp = Ws + 2;
-    const int groups = C / 4;
+    const int groups = Cp / 4;   // the channel padding (C <= c < Cp) is written as zeros
     // torch's area_pixel_compute_scale for align_corners: (in - 1) / (out - 1), 0 for a single output pixel
     const float sh = H > 1 ? float(Hs - 1) / float(H - 1) : 0.f, sw = W > 1 ? float(Ws - 1) / float(W - 1) : 0.f;
     const long long total = (long long)n * H * W * groups;
@@ -117,8 +117,14 @@ __global__ __launch_bounds__(256) void upsample_add_planes_kernel(const float* _
         auto at = [&](int yy, int xx) {
             return *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hsp + yy + 1) * Wsp + xx + 1) * lds + c);
         };
-        const f32x4 v00 = at(y0, x0), v01 = at(y0, x1), v10 = at(y1, x0), v11 = at(y1, x1);
         const size_t prow = ((size_t)b * Hp + y + 1) * Wp + x + 1;
+        _Float16* o = out + prow * 2 * Cp + (c >> 5) * 64 + (c & 31);
+        if (c >= C) {
+            *reinterpret_cast<f16x4*>(o) = f16x4{0, 0, 0, 0};
+            *reinterpret_cast<f16x4*>(o + 32) = f16x4{0, 0, 0, 0};
+            continue;
+        }
+        const f32x4 v00 = at(y0, x0), v01 = at(y0, x1), v10 = at(y1, x0), v11 = at(y1, x1);
         const f32x4 l = *reinterpret_cast<const f32x4*>(lat + prow * ldl + c);
         f32x4 v;
 #pragma unroll
@@ -131,7 +137,6 @@ __global__ __launch_bounds__(256) void upsample_add_planes_kernel(const float* _
         }
         f16x4 hi, lo;
         pope_split4(v * A_SCALE, hi, lo);
-        _Float16* o = out + prow * 2 * Cp + (c >> 5) * 64 + (c & 31);
         *reinterpret_cast<f16x4*>(o) = hi;
         *reinterpret_cast<f16x4*>(o + 32) = lo;
     }
@@ -192,10 +197,9 @@ int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
         buf[b] = base;
         base += align256(p.rows[kBufs[b].level] * kBufs[b].pitch * 4);
     }
-    // borders and the channel padding (196 -> 224) must read as zeros: clear everything once per call
-    if (hipMemsetAsync(q.ws, 0, size_t(base - static_cast<char*>(q.ws)), stream) != hipSuccess) return POPE_ERR_LAUNCH;
-    if (hipMemsetAsync(q.out_c, 0, p.rows[3] * 256 * 4, stream) != hipSuccess) return POPE_ERR_LAUNCH;
-    if (hipMemsetAsync(q.out_f, 0, p.rows[1] * 128 * 4, stream) != hipSuccess) return POPE_ERR_LAUNCH;
+    // Borders and the channel padding (196 -> 224) must read as zeros.  Nothing is cleared wholesale: every planes
+    // buffer is written in full by its producer — the GEMM epilogue zero-fills the padding columns, the gathers and
+    // the FPN merge write zeros where they have no source — and has its border rows zeroed right after.
 
     int rc;
     // generic GEMM over pixel rows: out[rows, N] = act(A[rows, K] . W^T + bias)
@@ -276,16 +280,18 @@ int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
         hipLaunchKernelGGL(upsample_add_planes_kernel, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const float*>(buf[F2]),
                            256, q.out_c, 256, reinterpret_cast<_Float16*>(buf[T2A]), 256, 256, q.n, p.Hp[2], p.Wp[2], q.range_flag);
         if ((rc = pope_check_launch())) return rc;
+        if ((rc = zero_border(buf[T2A], 2, 256))) return rc;
     }
     if ((rc = conv3(T2A, 17, 256, 2, T2B, 0.01f, -1))) return rc;
     if ((rc = gemm(buf[T2B], 9 * 256, 18, 196, 2, nullptr, reinterpret_cast<float*>(buf[X2O]), 224, 1.f, nullptr, 0, true, 256))) return rc;
     if ((rc = gemm(buf[P1B], 128, 19, 196, 1, nullptr, reinterpret_cast<float*>(buf[F1]), 224, 1.f, nullptr, 0, false, 128))) return rc;
     {
-        const long long total = (long long)q.n * (p.Hp[1] - 2) * (p.Wp[1] - 2) * (196 / 4);
+        const long long total = (long long)q.n * (p.Hp[1] - 2) * (p.Wp[1] - 2) * (224 / 4);
         hipLaunchKernelGGL(upsample_add_planes_kernel, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const float*>(buf[F1]),
                            224, reinterpret_cast<const float*>(buf[X2O]), 224, reinterpret_cast<_Float16*>(buf[T1A]), 224, 196, q.n,
                            p.Hp[1], p.Wp[1], q.range_flag);
         if ((rc = pope_check_launch())) return rc;
+        if ((rc = zero_border(buf[T1A], 1, 224))) return rc;
     }
     if ((rc = conv3(T1A, 20, 196, 1, T1B, 0.01f, -1))) return rc;
     return gemm(buf[T1B], 9 * 224, 21, 128, 1, nullptr, q.out_f, 128, 1.f, nullptr, 0, true, 224);                         // x1_out

@@ -314,6 +314,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
         const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
         const int col = n0 + wn * 64 + ec4;
         const bool col_ok = col < g.N;
+        // EPI_CONV planes rows are wider than N when the channel count is not a multiple of 32 (196 -> 224): the
+        // padding columns are the next convolution's K range and must read as zeros
+        const bool col_pad = EPI == EPI_CONV && OUT_PLANES && !col_ok && col < g.ldc;
         const int colc = col_ok ? col : 0;
         f32x4 bias = {0.f, 0.f, 0.f, 0.f}, gamma = {0.f, 0.f, 0.f, 0.f};
         if (g.bias) bias = *reinterpret_cast<const f32x4*>(g.bias + colc);
@@ -374,8 +377,11 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
                     f16x4 hi, lo;
                     pope_amax4x2(amax, v);
                     pope_split4(v * A_SCALE, hi, lo);
+                    if constexpr (EPI == EPI_CONV) {
+                        if (col_pad) { hi = f16x4{0, 0, 0, 0}; lo = f16x4{0, 0, 0, 0}; }
+                    }
                     // planes row: per 32-column chunk [32 hi | 32 lo] halves
-                    const unsigned o = col_ok ? off + unsigned((col >> 5) * 128 + (col & 31) * 2) : DROP;
+                    const unsigned o = col_ok || col_pad ? off + unsigned((col >> 5) * 128 + (col & 31) * 2) : DROP;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rc, o, 0, 2);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rc, o + 64u, 0, 2);
                 } else {
