@@ -361,17 +361,28 @@ class LocalFeatureTransformer(nn.Module):
         for name in self.layer_names:
             if name not in ("self", "cross"):
                 raise KeyError(name)
-        f0, f1 = feat0.float().contiguous().clone(), feat1.float().contiguous().clone()
-        n, L, C = f0.shape
-        S = f1.shape[1]
+        n, L, C = feat0.shape
+        S = feat1.shape[1]
         lib = _lib.lib()
-        nbytes = max(lib.pope_loftr_layer_workspace_bytes(n, a, b, C, self.nhead) for a in (L, S) for b in (L, S))
+        if L == S:
+            # both streams in ONE buffer: a 'self' layer treats them as a batch of 2n (same weights, independent
+            # sequences: one call instead of two — the layers are launch-bound at the drivers' batch of three pairs)
+            both = torch.cat([feat0.float(), feat1.float()], 0).contiguous()
+            f0, f1 = both[:n], both[n:]
+        else:
+            both = None
+            f0, f1 = feat0.float().contiguous().clone(), feat1.float().contiguous().clone()
+        nbytes = max(lib.pope_loftr_layer_workspace_bytes(2 * n if both is not None else n, a, b, C, self.nhead)
+                     for a in (L, S) for b in (L, S))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=f0.device)
         flags = []
         for layer, name in zip(self.layers, self.layer_names):
             if name == "self":
-                flags.append(layer.update_(f0, f0, ws))
-                flags.append(layer.update_(f1, f1, ws))
+                if both is not None:
+                    flags.append(layer.update_(both, both, ws))
+                else:
+                    flags.append(layer.update_(f0, f0, ws))
+                    flags.append(layer.update_(f1, f1, ws))
             else:
                 flags.append(layer.update_(f0, f1, ws))
                 flags.append(layer.update_(f1, f0, ws))
