@@ -253,6 +253,29 @@ int pope_resnetfpn_forward_f32(const pope_resnetfpn_weights* w_host, const float
                                float* out_c, float* out_f, void* workspace, size_t workspace_bytes,
                                unsigned* range_flag, void* stream);
 
+/* FinePreprocess.forward — src/matcher/loftr_module/fine_preprocess.py:29-59 (fine_concat_coarse_feat = True), for
+ * M > 0 matches: Wn x Wn windows (zero padded by Wn/2) of the 1/2-resolution maps centred on the matched coarse
+ * cells (i_ids in map 0, j_ids in map 1; cell id = cy * wc + cx, centre pixel = cell * stride), concatenated with
+ * down_proj(coarse feature of the cell) and passed through merge_feat.  Only the M matched windows are gathered (the
+ * reference unfolds all of them first).  feat_f*: fp32 maps addressed through ELEMENT strides strides*_host[4] =
+ * (n, c, h, w), so NCHW tensors and NHWC views both work; feat_c0[n,L,Cc], feat_c1[n,S,Cc]; b/i/j_ids: int64[M];
+ * down_wp[Cf,Cc], merge_wp[Cf,2*Cf]: weight planes (scale 256), biases fp32; out[2*M, Wn*Wn, Cf] = windows of
+ * stream 0 then stream 1 (the reference's torch.chunk(…, 2)). */
+size_t pope_fine_preprocess_workspace_bytes(int M, int Wn, int Cc, int Cf);
+int pope_fine_preprocess_f32(const float* feat_f0, const long long* strides0_host, int H0, int W0, int wc0,
+                             const float* feat_f1, const long long* strides1_host, int H1, int W1, int wc1,
+                             const float* feat_c0, const float* feat_c1, int L, int S, int Cc, int Cf,
+                             const long long* b_ids, const long long* i_ids, const long long* j_ids, int M,
+                             int Wn, int stride, const void* down_wp, const float* down_b, const void* merge_wp,
+                             const float* merge_b, float* out, void* workspace, size_t workspace_bytes,
+                             unsigned* range_flag, void* stream);
+/* FineMatching.forward + get_fine_match — src/matcher/utils/fine_matching.py:15-74 for M > 0: correlation of the
+ * centre of window 0 with window 1 (temperature 1/sqrt(C)), softmax, expectation over linspace(-1,1,Wn)^2 as (x, y)
+ * and the summed standard deviation -> expec_f[M,3]; mkpts1_f[M,2] = mkpts1_c + expec_xy * (Wn/2) * scale_px
+ * (scale_px = hw0_i[0] / hw0_f[0]).  win0, win1: [M, Wn*Wn, C] fp32 (the fine transformer's outputs). */
+int pope_fine_match_f32(const float* win0, const float* win1, int M, int Wn, int C, const float* mkpts1_c,
+                        float scale_px, float* expec_f, float* mkpts1_f, void* stream);
+
 /* ---- caller-side preprocessing, batched ------------------------------------------------- */
 
 /* set_torch_image for P crops at once — segment_anything/segment_anything/dinov2_utils.py:55-78: Resize (Pillow's

@@ -89,6 +89,12 @@ PROTOTYPES = {
     "pope_resnetfpn_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "pope_resnetfpn_forward_f32": (C.c_int, [C.POINTER(ResnetFpnWeights), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "pope_fine_preprocess_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "pope_fine_preprocess_f32": (C.c_int, [C.c_void_p, c_ll_p, C.c_int, C.c_int, C.c_int, C.c_void_p, c_ll_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3 + [C.c_int] * 3
+                                 + [C.c_void_p] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "pope_fine_match_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
     "pope_preprocess_u8_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3
                                + [C.c_int] * 7 + [c_float_p, c_float_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pope_gray_u8_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -530,6 +530,35 @@ int pope_resnetfpn_forward_f32(const pope_resnetfpn_weights* w, const float* gra
     return pope_launch_resnetfpn(q, static_cast<hipStream_t>(stream));
 }
 
+size_t pope_fine_preprocess_workspace_bytes(int M, int Wn, int Cc, int Cf) {
+    if (M <= 0 || Wn <= 0 || Cc <= 0 || Cf <= 0) return 0;
+    return pope_fine_preprocess_workspace(M, Wn * Wn, Cc, Cf);
+}
+
+int pope_fine_preprocess_f32(const float* feat_f0, const long long* strides0, int H0, int W0, int wc0, const float* feat_f1,
+                             const long long* strides1, int H1, int W1, int wc1, const float* feat_c0, const float* feat_c1, int L,
+                             int S, int Cc, int Cf, const long long* b_ids, const long long* i_ids, const long long* j_ids, int M, int Wn,
+                             int stride, const void* down_wp, const float* down_b, const void* merge_wp, const float* merge_b,
+                             float* out, void* workspace, size_t workspace_bytes, unsigned* range_flag, void* stream) {
+    StreamDevice on_device(stream);
+    if (!strides0 || !strides1 || H0 <= 0 || W0 <= 0 || H1 <= 0 || W1 <= 0 || wc0 <= 0 || wc1 <= 0 || L <= 0 || S <= 0) return POPE_ERR_ARG;
+    FinePreParams q = {};
+    q.f0 = feat_f0; q.f1 = feat_f1;
+    for (int i = 0; i < 4; ++i) { q.s0[i] = strides0[i]; q.s1[i] = strides1[i]; }
+    q.H0 = H0; q.W0 = W0; q.H1 = H1; q.W1 = W1; q.wc0 = wc0; q.wc1 = wc1;
+    q.fc0 = feat_c0; q.fc1 = feat_c1; q.L = L; q.S = S; q.Cc = Cc; q.Cf = Cf;
+    q.b_ids = b_ids; q.i_ids = i_ids; q.j_ids = j_ids; q.M = M; q.Wn = Wn; q.stride = stride;
+    q.down_wp = down_wp; q.down_b = down_b; q.merge_wp = merge_wp; q.merge_b = merge_b;
+    q.out = out; q.ws = workspace; q.ws_bytes = workspace_bytes; q.range_flag = range_flag;
+    return pope_launch_fine_preprocess(q, static_cast<hipStream_t>(stream));
+}
+
+int pope_fine_match_f32(const float* win0, const float* win1, int M, int Wn, int C, const float* mkpts1_c, float scale_px,
+                        float* expec_f, float* mkpts1_f, void* stream) {
+    StreamDevice on_device(stream);
+    return pope_launch_fine_match(win0, win1, M, Wn, C, mkpts1_c, scale_px, expec_f, mkpts1_f, static_cast<hipStream_t>(stream));
+}
+
 int pope_preprocess_u8_f32(const unsigned char* img_hwc, int P, int Hin, int Win, const int* hstart, const int* hcount,
                            const int* hk, int kh, const int* vstart, const int* vcount, const int* vk, int kv, int top, int left,
                            int ch, int cw, int row0, int nrows, const float* mean_host, const float* std_host, float* out,

@@ -192,5 +192,25 @@ struct ResnetFpnParams {
 };
 size_t pope_resnetfpn_workspace(int n, int H, int W);
 int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream);
+// LoFTR fine stage (fine.hip; fine_preprocess.py:29-59, fine_matching.py:15-74)
+struct FinePreParams {
+    const float *f0, *f1;          // 1/2-resolution maps, addressed through element strides (n, c, h, w)
+    long long s0[4], s1[4];
+    int H0, W0, H1, W1;            // map sizes
+    int wc0, wc1;                  // coarse grid widths (cell id = cy * wc + cx)
+    const float *fc0, *fc1;        // [n, L, Cc], [n, S, Cc] coarse features after the coarse transformer
+    int L, S, Cc, Cf;
+    const long long *b_ids, *i_ids, *j_ids;   // [M] matches (device)
+    int M, Wn, stride;             // window size (5), fine pixels per coarse cell
+    const void *down_wp, *merge_wp;   // [Cf, Cc], [Cf, 2 Cf] weight planes
+    const float *down_b, *merge_b;
+    float* out;                    // [2 M, Wn * Wn, Cf]: windows of stream 0, then of stream 1
+    void* ws; size_t ws_bytes;
+    unsigned* range_flag;
+};
+size_t pope_fine_preprocess_workspace(int M, int WW, int Cc, int Cf);
+int pope_launch_fine_preprocess(const FinePreParams& q, hipStream_t stream);
+int pope_launch_fine_match(const float* win0, const float* win1, int M, int Wn, int C, const float* mkpts1_c, float scale_px,
+                           float* expec, float* mkpts1_f, hipStream_t stream);
 size_t pope_loftr_layer_workspace(int n, int L, int S, int C, int H);
 int pope_launch_loftr_layer(const LoftrLayerParams& p, hipStream_t stream);

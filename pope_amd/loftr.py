@@ -435,6 +435,60 @@ class FinePreprocess(nn.Module):
         for p in self.parameters():  # fine_preprocess.py:24-27
             if p.dim() > 1:
                 nn.init.kaiming_normal_(p, mode="fan_out", nonlinearity="relu")
+        self._hip = None
+        self.use_hip = True   # dev / test switch: False = the torch form on any device
+
+    def _apply(self, fn, *a, **k):
+        self._hip = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._hip = None
+        return super().load_state_dict(*a, **k)
+
+    def _forward_hip(self, feat_f0, feat_f1, feat_c0, feat_c1, data, stride):
+        """One C-ABI call (pope_fine_preprocess_f32, fine.hip): gathers + the two Linears on the planes GEMM.  None when a
+        weight or an activation leaves the f16x3 range (the torch form then runs)."""
+        import ctypes as C
+        from . import _lib
+        key = self.down_proj.weight.data_ptr()
+        if self._hip is None or self._hip[0] != key:
+            ws_ = [self.down_proj.weight.detach().float(), self.merge_feat.weight.detach().float()]
+            if not max(float(t.abs().max()) for t in ws_) * _lib.PLANES_W_SCALE < _lib.F16_MAX:
+                self._hip = (key, None)
+            else:
+                self._hip = (key, [_lib.to_planes(t, _lib.PLANES_W_SCALE) for t in ws_]
+                             + [self.down_proj.bias.detach().float().contiguous(), self.merge_feat.bias.detach().float().contiguous()])
+        if self._hip[1] is None:
+            return None
+        dwp, mwp, db, mb = self._hip[1]
+        b, i, j = (t.contiguous() for t in (data["b_ids"], data["i_ids"], data["j_ids"]))
+        M, W, Cf = int(b.shape[0]), self.W, self.d_model_f
+        fc0, fc1 = feat_c0.float().contiguous(), feat_c1.float().contiguous()
+        f0, f1 = feat_f0.float(), feat_f1.float()
+        dev = f0.device
+        out = torch.empty(2 * M, W * W, Cf, dtype=torch.float32, device=dev)
+        lib = _lib.lib()
+        nbytes = lib.pope_fine_preprocess_workspace_bytes(M, W, fc0.shape[2], Cf)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        s0, s1 = (C.c_longlong * 4)(*f0.stride()), (C.c_longlong * 4)(*f1.stride())
+        with _lib.on_device_of(f0):
+            _lib.check(lib.pope_fine_preprocess_f32(
+                C.c_void_p(f0.data_ptr()), s0, f0.shape[2], f0.shape[3], int(data["hw0_c"][1]),
+                C.c_void_p(f1.data_ptr()), s1, f1.shape[2], f1.shape[3], int(data["hw1_c"][1]),
+                C.c_void_p(fc0.data_ptr()), C.c_void_p(fc1.data_ptr()), fc0.shape[1], fc1.shape[1], fc0.shape[2], Cf,
+                C.c_void_p(b.data_ptr()), C.c_void_p(i.data_ptr()), C.c_void_p(j.data_ptr()), M, W, int(stride),
+                C.c_void_p(dwp.data_ptr()), C.c_void_p(db.data_ptr()), C.c_void_p(mwp.data_ptr()), C.c_void_p(mb.data_ptr()),
+                C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(flag.data_ptr()), _lib.stream_of(dev)),
+                "pope_fine_preprocess_f32")
+        bits = int(flag.item())
+        if bits:
+            import warnings
+            warnings.warn(f"pope_amd: f16x3 range contract breached in the LoFTR fine preprocess ({_lib.describe_range_bits(bits)}); "
+                          "re-running it in torch fp32")
+            return None
+        return out[:M], out[M:]
 
     def forward(self, feat_f0, feat_f1, feat_c0, feat_c1, data):
         W = self.W
@@ -444,6 +498,10 @@ class FinePreprocess(nn.Module):
         if b.shape[0] == 0:
             empty = torch.empty(0, W * W, self.d_model_f, device=feat_f0.device)
             return empty, empty.clone()
+        if self.use_hip and self.cat_c_feat and feat_f0.is_cuda and W * W <= 64:
+            out = self._forward_hip(feat_f0, feat_f1, feat_c0, feat_c1, data, stride)
+            if out is not None:
+                return out
         # NB the reference unfolds image 1 with image 0's stride and both with their own width (:44-47)
         win0 = gather_windows(feat_f0, b, i, data["hw0_c"][1], W, stride)
         win1 = gather_windows(feat_f1, b, j, data["hw1_c"][1], W, stride)
@@ -466,6 +524,20 @@ class FineMatching(nn.Module):
         if M == 0:
             data.update({"expec_f": torch.empty(0, 3, device=feat_f0.device),
                          "mkpts0_f": data["mkpts0_c"], "mkpts1_f": data["mkpts1_c"]})
+            return
+        if getattr(self, "use_hip", True) and feat_f0.is_cuda and "scale0" not in data and WW <= 64 and len(data["mconf"]) == M:
+            import ctypes
+            from . import _lib
+            w0, w1 = feat_f0.float().contiguous(), feat_f1.float().contiguous()
+            mk1c = data["mkpts1_c"].float().contiguous()
+            expec = torch.empty(M, 3, dtype=torch.float32, device=w0.device)
+            mk1f = torch.empty(M, 2, dtype=torch.float32, device=w0.device)
+            with _lib.on_device_of(w0):
+                _lib.check(_lib.lib().pope_fine_match_f32(
+                    ctypes.c_void_p(w0.data_ptr()), ctypes.c_void_p(w1.data_ptr()), M, W, C, ctypes.c_void_p(mk1c.data_ptr()),
+                    float(scale), ctypes.c_void_p(expec.data_ptr()), ctypes.c_void_p(mk1f.data_ptr()), _lib.stream_of(w0.device)),
+                    "pope_fine_match_f32")
+            data.update({"expec_f": expec, "mkpts0_f": data["mkpts0_c"], "mkpts1_f": mk1f})
             return
         sim = torch.einsum("mc,mrc->mr", feat_f0[:, WW // 2, :], feat_f1)
         heat = torch.softmax(sim * (1.0 / C ** 0.5), dim=1)                          # [M, WW]

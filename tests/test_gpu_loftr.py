@@ -253,3 +253,69 @@ def test_hip_backbone_range_guard_falls_back(dev):
     assert bool(torch.isfinite(a[0]).all())
     for u, v in zip(a, c):
         assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max())
+
+
+# ---- the HIP fine stage: window gather + down_proj / merge_feat, and the sub-pixel expectation ------
+
+def _fine_modules(dev):
+    from pope_amd import synth
+    from pope_amd.loftr import FinePreprocess, FineMatching
+    from pope_amd.matcher import default_cfg
+    fp = FinePreprocess(default_cfg).eval()
+    sd = synth.synthetic_matcher_state_dict(seed=0)
+    fp.load_state_dict({k[len("fine_preprocess."):]: v for k, v in sd.items() if k.startswith("fine_preprocess.")}, strict=True)
+    return fp.to(dev), FineMatching()
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc_view"])
+@pytest.mark.parametrize("M", [1, 37, 600])
+def test_hip_fine_preprocess_matches_torch_form(dev, layout, M):
+    """pope_fine_preprocess_f32 against the torch restatement of fine_preprocess.py:29-59 (itself pinned to the reference by
+    the Matcher fixtures): windows at random cells incl. the map's corners (zero padding), both memory layouts."""
+    fp, _ = _fine_modules(dev)
+    g = torch.Generator().manual_seed(M)
+    n, hc, wc, s = 2, 12, 16, 4
+    hf, wf = hc * s, wc * s
+    if layout == "nchw":
+        f0, f1 = torch.randn(n, 128, hf, wf, generator=g).to(dev), torch.randn(n, 128, hf, wf, generator=g).to(dev)
+    else:   # what the HIP backbone hands over: the interior of a bordered NHWC buffer, permuted
+        f0 = torch.randn(n, hf + 2, wf + 2, 128, generator=g).to(dev)[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)
+        f1 = torch.randn(n, hf + 2, wf + 2, 128, generator=g).to(dev)[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)
+    c0, c1 = torch.randn(n, hc * wc, 256, generator=g).to(dev), torch.randn(n, hc * wc, 256, generator=g).to(dev)
+    b = torch.randint(0, n, (M,), generator=g).sort().values
+    i = torch.randint(0, hc * wc, (M,), generator=g)
+    j = torch.randint(0, hc * wc, (M,), generator=g)
+    i[0], j[0] = 0, hc * wc - 1                         # corners: windows reach outside the map
+    data = {"hw0_f": (hf, wf), "hw0_c": (hc, wc), "hw1_c": (hc, wc), "b_ids": b.to(dev), "i_ids": i.to(dev), "j_ids": j.to(dev)}
+    with torch.no_grad():
+        g0, g1 = fp(f0, f1, c0, c1, dict(data))
+        fp.use_hip = False
+        w0, w1 = fp(f0, f1, c0, c1, dict(data))
+        r0, r1 = copy.deepcopy(fp).cpu().double()(f0.cpu().double(), f1.cpu().double(), c0.cpu().double(), c1.cpu().double(),
+                                                  {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in data.items()})
+    assert g0.shape == (M, 25, 128) and g1.shape == (M, 25, 128)
+    e_hip = max(float((g0.cpu().double() - r0).abs().max()), float((g1.cpu().double() - r1).abs().max()))
+    e_torch = max(float((w0.cpu().double() - r0).abs().max()), float((w1.cpu().double() - r1).abs().max()))
+    print(f"fine preprocess M={M} {layout}: max err HIP {e_hip:.2e}, torch fp32 {e_torch:.2e}")
+    assert e_hip < 4 * e_torch + 2e-5
+
+
+@pytest.mark.parametrize("M", [1, 5, 333])
+def test_hip_fine_matching_matches_torch_form(dev, M):
+    _, fm = _fine_modules(dev)
+    g = torch.Generator().manual_seed(100 + M)
+    w0, w1 = torch.randn(M, 25, 128, generator=g).to(dev), torch.randn(M, 25, 128, generator=g).to(dev)
+    w1[:, 7] = w0[:, 12] * 1.5                        # a clear peak off the centre
+    mk = (torch.rand(M, 2, generator=g) * 200).to(dev)
+    base = {"hw0_i": (256, 256), "hw0_f": (128, 128), "mkpts0_c": mk.clone(), "mkpts1_c": mk.clone(), "mconf": torch.ones(M, device=dev),
+            "b_ids": torch.zeros(M, dtype=torch.long, device=dev)}
+    a, b = dict(base), dict(base)
+    fm(w0, w1, a)
+    fm.use_hip = False
+    fm(w0, w1, b)
+    torch.testing.assert_close(a["expec_f"][:, :2], b["expec_f"][:, :2], rtol=1e-5, atol=1e-5)
+    # the spread is sqrt(E[g^2] - E[g]^2) per axis (fine_matching.py:52-54): for a peaked heatmap the difference cancels
+    # to fp32 noise (~1e-7) and its square root amplifies that to ~3e-4 — in the reference's own arithmetic too
+    torch.testing.assert_close(a["expec_f"][:, 2], b["expec_f"][:, 2], rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(a["mkpts1_f"], b["mkpts1_f"], rtol=1e-6, atol=1e-4)
+    assert torch.equal(a["mkpts0_f"], b["mkpts0_f"])
