@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true",
                     help="profiling only: skip the self-check (its batch-1 launches would enter rocprof's per-kernel averages); "
                          "the line then carries \"verified\": null")
+    ap.add_argument("--from-host", action="store_true",
+                    help="add a leg that starts from uint8 640x480 frames in pinned HOST memory (PCIe upload on a copy stream, "
+                         "crop + normalise on the GPU); reported as `from_host`, never as `value`")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the ViT chunks of a step are spread over")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="dev: run the N-rank code path with every rank on cuda:0 and the gloo backend (collectives on "
@@ -332,6 +335,8 @@ def main():
     # ---- N = 1 extras: strict-fp32 leg (driver-observed figure for the fp32-MFMA mode) and the CPU oracle -------
     if rank == 0 and world == 1 and not linemod and args.precision != "f32" and not args.no_strict_f32:
         result["strict_f32"] = strict_f32_leg(model, pipe, img0, img1, args)
+    if rank == 0 and world == 1 and not linemod and args.from_host:
+        result["from_host"] = from_host_leg(pipe, args, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N = 1 only (the other ranks would idle)
         result["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
     if world > 1:
@@ -341,6 +346,56 @@ def main():
         print(json.dumps(result))
     if verified is False:
         raise SystemExit(3)
+
+
+def from_host_leg(pipe, args, device, steps=4):
+    """The same step when the inputs are uint8 frames in pinned host memory (what a capture or decode stage hands over):
+    per step 2 x pairs frames of 640x480x3 bytes cross PCIe on a copy stream into one of two device staging buffers while
+    the previous step computes; centre crop 476x630 + ToTensor + Normalize is one kernel (pope_crop_normalize_u8_f32).
+    DESIGN.md §5: this PCIe-inclusive rate is reported next to `value`, never as `value`."""
+    from pope_amd.preprocess import crop_normalize
+    n = args.pairs
+    g = torch.Generator().manual_seed(5)
+    host = []
+    for _ in range(2):   # second frame of a pair = the first one shifted by (14, 28) pixels: the matcher has work to do
+        a = torch.randint(0, 256, (n, 480, 640, 3), dtype=torch.uint8, generator=g)
+        host.append(torch.cat([a, torch.roll(a, shifts=(14, 28), dims=(1, 2))], 0).pin_memory())
+    stage = [torch.empty(2 * n, 480, 640, 3, dtype=torch.uint8, device=device) for _ in range(2)]
+    x = torch.empty(2 * n, 3, H_IMG, W_IMG, dtype=torch.float32, device=device)
+    copy_stream = torch.cuda.Stream(device)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    freed = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(k):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(freed[k & 1])            # the compute stream is done with this staging buffer
+            stage[k & 1].copy_(host[k & 1], non_blocking=True)
+            ready[k & 1].record(copy_stream)
+
+    def compute(k):
+        cur = torch.cuda.current_stream(device)
+        cur.wait_event(ready[k & 1])
+        crop_normalize(stage[k & 1], (H_IMG, W_IMG), out=x)
+        freed[k & 1].record(cur)
+        return pipe(x[:n], x[n:])
+
+    for e in freed:
+        e.record(torch.cuda.current_stream(device))
+    upload(0)
+    upload(1)
+    compute(0)                                               # warm-up
+    torch.cuda.synchronize(device)
+    upload(2)
+    t0 = time.perf_counter()
+    for k in range(1, 1 + steps):
+        out = compute(k)
+        upload(k + 2)                                        # two uploads ahead of the step that consumes them
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(n / dt, 2), "unit": "image-pairs/s", "steps": steps, "ms_per_step": round(dt * 1e3, 3),
+            "host_bytes_per_step": 2 * n * 480 * 640 * 3, "matches_per_pair_mean": round(float(out["counts"].float().mean()), 1),
+            "note": "uint8 640x480 frames in pinned host memory -> async H2D on a copy stream (double-buffered) -> GPU crop + "
+                    "normalise -> the same extract + match step; PCIe-inclusive, not the headline"}
 
 
 def roofline_entry(dominant, dom, peak_tflops, mfma_factor, chunk):

@@ -291,6 +291,11 @@ int pope_preprocess_u8_f32(const unsigned char* img_hwc, int P, int Hin, int Win
                            int top, int left, int ch, int cw, int row0, int nrows,
                            const float* mean_host, const float* std_host, float* out,
                            unsigned char* scratch, size_t scratch_bytes, void* stream);
+/* ToTensor + Normalize of a crop window without resizing (torchvision semantics: x / 255, then (x - mean) / std in
+ * fp32) — the dense pair path's 476 x 630 centre crop of a 640 x 480 frame: img_hwc[P,Hin,Win,3] uint8 ->
+ * out[P,3,ch,cw] fp32 (16-byte aligned); mean_host / std_host[3] = HOST floats in the channel order of img. */
+int pope_crop_normalize_u8_f32(const unsigned char* img_hwc, int P, int Hin, int Win, int top, int left, int ch, int cw,
+                               const float* mean_host, const float* std_host, float* out, void* stream);
 /* cv2.cvtColor(BGR2GRAY) (8-bit fixed point) followed by / 255. — eval_linemod_json.py:103-111:
  * bgr_hwc[P,H,W,3] uint8 -> out[P,1,H,W] fp32 in [0,1] (the Matcher's input). */
 int pope_gray_u8_f32(const unsigned char* bgr_hwc, int P, int H, int W, float* out, void* stream);

@@ -97,6 +97,7 @@ PROTOTYPES = {
                                       C.c_void_p, C.c_void_p]),
     "pope_preprocess_u8_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3
                                + [C.c_int] * 7 + [c_float_p, c_float_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pope_crop_normalize_u8_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [c_float_p, c_float_p, C.c_void_p, C.c_void_p]),
     "pope_gray_u8_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pope_streaming_top3_host": (C.c_int, [c_float_p, C.c_int, c_float_p, c_ll_p]),
 }

@@ -576,6 +576,12 @@ int pope_preprocess_u8_f32(const unsigned char* img_hwc, int P, int Hin, int Win
     return pope_launch_preprocess(p, static_cast<hipStream_t>(stream));
 }
 
+int pope_crop_normalize_u8_f32(const unsigned char* img_hwc, int P, int Hin, int Win, int top, int left, int ch, int cw,
+                               const float* mean_host, const float* std_host, float* out, void* stream) {
+    StreamDevice on_device(stream);
+    return pope_launch_crop_norm(img_hwc, P, Hin, Win, top, left, ch, cw, mean_host, std_host, out, static_cast<hipStream_t>(stream));
+}
+
 int pope_gray_u8_f32(const unsigned char* bgr_hwc, int P, int H, int W, float* out, void* stream) {
     StreamDevice on_device(stream);
     if (P <= 0 || H <= 0 || W <= 0) return POPE_ERR_ARG;

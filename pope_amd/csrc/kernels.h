@@ -167,6 +167,8 @@ struct PreprocParams {
 };
 int pope_launch_preprocess(const PreprocParams& p, hipStream_t stream);
 int pope_launch_gray(const unsigned char* bgr, size_t npix, float* out, hipStream_t stream);
+int pope_launch_crop_norm(const unsigned char* img, int P, int Hin, int Win, int top, int left, int ch, int cw, const float* mean,
+                          const float* std, float* out, hipStream_t stream);
 
 // One LoFTR encoder layer update (loftr.hip): x <- layer(x, source); weights as f16x3 planes (bias-free Linears)
 struct LoftrLayerParams {

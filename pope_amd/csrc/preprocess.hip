@@ -84,6 +84,34 @@ __global__ __launch_bounds__(256) void gray_kernel(const unsigned char* __restri
     }
 }
 
+// ToTensor + Normalize of a crop window, no resize (torchvision: x / 255, then (x - mean) / std, fp32): the dense
+// pair path feeds 476 x 630 centre crops of 640 x 480 frames.  [P, Hin, Win, 3] uint8 -> [P, 3, ch, cw] fp32; a thread
+// converts four pixels of a row (12 input bytes, three 16-byte stores when cw % 4 == 0)
+__global__ __launch_bounds__(256) void crop_norm_kernel(const unsigned char* __restrict__ img, int P, int Hin, int Win, int top,
+                                                        int left, int ch, int cw, float m0, float m1, float m2, float s0, float s1,
+                                                        float s2, float* __restrict__ out) {
+    const int qw = (cw + 3) / 4;
+    const size_t total = size_t(P) * ch * qw, plane = size_t(ch) * cw;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += size_t(gridDim.x) * 256) {
+        const int xq = int(i % qw);
+        const size_t py = i / qw;
+        const int y = int(py % ch), p = int(py / ch);
+        const unsigned char* q = img + ((size_t(p) * Hin + top + y) * Win + left + 4 * xq) * 3;
+        float* o = out + size_t(p) * 3 * plane + size_t(y) * cw + 4 * xq;
+        const int nx = cw - 4 * xq < 4 ? cw - 4 * xq : 4;
+        float r[3][4];
+        for (int e = 0; e < nx; ++e) {
+            r[0][e] = (float(q[3 * e]) / 255.0f - m0) / s0;
+            r[1][e] = (float(q[3 * e + 1]) / 255.0f - m1) / s1;
+            r[2][e] = (float(q[3 * e + 2]) / 255.0f - m2) / s2;
+        }
+        for (int c = 0; c < 3; ++c) {
+            if (nx == 4 && !(cw & 3)) *reinterpret_cast<f32x4*>(o + c * plane) = f32x4{r[c][0], r[c][1], r[c][2], r[c][3]};
+            else for (int e = 0; e < nx; ++e) o[c * plane + e] = r[c][e];
+        }
+    }
+}
+
 inline unsigned grid_for(size_t n) { return unsigned(n / 256 + 1 < 16384 ? n / 256 + 1 : 16384); }
 
 }  // namespace
@@ -97,6 +125,16 @@ int pope_launch_preprocess(const PreprocParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(resize_v_norm_kernel, dim3(grid_for(size_t(p.P) * p.ch * p.cw)), dim3(256), 0, stream, p.tmp, p.P, p.row0,
                        p.nrows, p.vstart, p.vcount, p.vk, p.kv, p.top, p.ch, p.cw, p.mean[0], p.mean[1], p.mean[2], p.std[0],
                        p.std[1], p.std[2], p.out);
+    return pope_check_launch();
+}
+
+int pope_launch_crop_norm(const unsigned char* img, int P, int Hin, int Win, int top, int left, int ch, int cw, const float* mean,
+                          const float* std, float* out, hipStream_t stream) {
+    if (!img || !out || !mean || !std || P <= 0 || ch <= 0 || cw <= 0 || top < 0 || left < 0 || top + ch > Hin || left + cw > Win)
+        return POPE_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(out) & 15) return POPE_ERR_ARG;
+    hipLaunchKernelGGL(crop_norm_kernel, dim3(grid_for(size_t(P) * ch * ((cw + 3) / 4))), dim3(256), 0, stream, img, P, Hin, Win, top,
+                       left, ch, cw, mean[0], mean[1], mean[2], std[0], std[1], std[2], out);
     return pope_check_launch();
 }
 

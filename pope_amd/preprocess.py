@@ -100,6 +100,27 @@ def set_torch_images(images, center_crop=False, device="cuda"):
 
 
 @torch.no_grad()
+def crop_normalize(images, crop_hw, mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None):
+    """[P, H, W, 3] uint8 (CUDA) -> [P, 3, ch, cw] fp32: the centre crop + ToTensor + Normalize of the dense pair path (640 x 480
+    frames -> 476 x 630, no resize), one kernel, bit-equal to torchvision's fp32 arithmetic.  `out` lets a pipeline reuse its
+    input buffer."""
+    require_cuda(images, "crop_normalize")
+    if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
+        raise TypeError("crop_normalize expects a uint8 [P, H, W, 3] tensor")
+    images = images.contiguous()
+    P, H, W, _ = images.shape
+    ch, cw = crop_hw
+    top, left = (H - ch) // 2, (W - cw) // 2
+    if out is None:
+        out = torch.empty(P, 3, ch, cw, dtype=torch.float32, device=images.device)
+    m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    with on_device_of(images):
+        check(_lib.lib().pope_crop_normalize_u8_f32(C.c_void_p(images.data_ptr()), P, H, W, top, left, ch, cw, m, s,
+                                                    C.c_void_p(out.data_ptr()), stream_of(images.device)), "pope_crop_normalize_u8_f32")
+    return out
+
+
+@torch.no_grad()
 def gray_batch(images_bgr):
     """[P, H, W, 3] uint8 BGR (CUDA) -> [P, 1, H, W] fp32 in [0, 1]: cv2.cvtColor(BGR2GRAY) (OpenCV's 8-bit fixed-point
     weights) / 255., the matcher's input (eval_linemod_json.py:103-111).  OpenCV is not in this image: the integer

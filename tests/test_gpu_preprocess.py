@@ -82,3 +82,18 @@ def test_driver_step_from_uint8_frames(dev, sd0):
     assert 2 in got["slot_index"] and got["best_proposal"] == want["best_proposal"]
     for s in range(3):
         assert np.array_equal(got["mkpts0"][s], want["mkpts0"][s]) and np.array_equal(got["mconf"][s], want["mconf"][s])
+
+
+def test_crop_normalize_matches_torchvision_arithmetic(dev):
+    """pope_crop_normalize_u8_f32 (the dense pair path's centre crop + ToTensor + Normalize, no resize) bit-for-bit against
+    the fp32 arithmetic of torchvision's ToTensor (x / 255) and Normalize ((x - mean) / std)."""
+    from pope_amd.preprocess import crop_normalize
+    from pope_amd.synth import IMAGENET_MEAN, IMAGENET_STD
+    g = torch.Generator().manual_seed(11)
+    for (P, H, W, ch, cw) in [(3, 480, 640, 476, 630), (2, 37, 53, 30, 41), (1, 8, 8, 8, 8)]:
+        img = torch.randint(0, 256, (P, H, W, 3), dtype=torch.uint8, generator=g)
+        got = crop_normalize(img.to(dev), (ch, cw)).cpu()
+        top, left = (H - ch) // 2, (W - cw) // 2
+        x = img[:, top:top + ch, left:left + cw, :].permute(0, 3, 1, 2).float() / 255.0
+        want = (x - torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)) / torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+        assert torch.equal(got, want), (P, H, W)
