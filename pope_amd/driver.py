@@ -29,8 +29,14 @@ def locate_and_match(dinov2_model, matcher, ref_tensor, crop_tensors, gray_ref, 
     conf_thr) (:121-122); `best_slot` = first argmax (:150) and `best_proposal`.
     A slot that was never filled (fewer than three proposals with a positive score) is skipped with
     matching_score 0; the reference raises on it (:109 indexes an empty list)."""
-    ref = get_cls_token_torch(dinov2_model, ref_tensor)
-    fea = get_cls_token_torch(dinov2_model, crop_tensors)
+    if ref_tensor.shape[1:] == crop_tensors.shape[1:]:
+        # one launch sequence for the reference image and the P proposals (the kernels are batch-invariant bit for bit,
+        # tests/test_gpu_vit.py: the tokens are those of the two separate forwards)
+        both = get_cls_token_torch(dinov2_model, torch.cat([ref_tensor, crop_tensors], 0))
+        ref, fea = both[:1], both[1:]
+    else:
+        ref = get_cls_token_torch(dinov2_model, ref_tensor)
+        fea = get_cls_token_torch(dinov2_model, crop_tensors)
     scores = cls_cosine(ref, fea, eps=1e-8)
     slot_scores, slot_index = streaming_top3(scores.cpu().numpy())
     filled = [s for s in range(3) if slot_index[s] >= 0]
