@@ -154,8 +154,16 @@ __global__ __launch_bounds__(256) void combine_col_stats_kernel(const MatchParam
 // ---- the one pass over the matrix -----------------------------------------------------------------------------------
 // conf(i, j) from sim and the four statistics: softmax(sim, dim=1) * softmax(sim, dim=2) (coarse_matching.py:119, in
 // that order).  ONE definition: conf_pass_kernel and the tie re-scan of select_kernel must produce the same bits.
+// exp(v - cmx) / csum * exp(v - rmx) / rsum with ONE exponential: exp((v - cmx) + (v - rmx)) * (cinv * rinv).  Both
+// differences are <= 0 and computed first (exact where it matters: near the maxima), so the exponent is as accurate as
+// in the two-exponential form; a product that underflowed there underflows here.  The pair form is the same arithmetic
+// in packed instructions (v_pk_add / v_pk_mul are IEEE-identical to the scalar ones; contraction is off).
 __device__ __forceinline__ float conf_value(float v, float cmx, float cinv, float rmx, float rinv) {
-    return (__builtin_amdgcn_exp2f((v - cmx) * L2E) * cinv) * (__builtin_amdgcn_exp2f((v - rmx) * L2E) * rinv);
+    return __builtin_amdgcn_exp2f(((v - cmx) + (v - rmx)) * L2E) * (cinv * rinv);
+}
+__device__ __forceinline__ f32x2 conf_value2(f32x2 v, f32x2 cmx, f32x2 cinv, float rmx, float rinv) {
+    const f32x2 t = ((v - cmx) + (v - f32x2{rmx, rmx})) * f32x2{L2E, L2E};
+    return f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} * (cinv * f32x2{rinv, rinv});
 }
 
 constexpr int CP_ROWS = 32;   // rows per workgroup: 8 per wave
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(256) void conf_pass_fast_kernel(const MatchParams p
             float m = 0.f;   // conf >= 0
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                c[k] = f32x2{conf_value(c[k][0], cmx[k][0], cinv[k][0], rmx, rinv), conf_value(c[k][1], cmx[k][1], cinv[k][1], rmx, rinv)};
+                c[k] = conf_value2(c[k], cmx[k], cinv[k], rmx, rinv);
                 cbest[k][0] = fmaxf(cbest[k][0], c[k][0]);
                 cbest[k][1] = fmaxf(cbest[k][1], c[k][1]);
                 m = fmaxf(m, fmaxf(c[k][0], c[k][1]));
