@@ -49,6 +49,17 @@ __device__ __forceinline__ float quad_sum(float v) {
     return a + b;
 }
 
+#ifdef RL_STAMPS  // dev: wall-clock stamps (10 ns ticks) of block 0, per kind of launch (K = 384 / 1536 / other), scripts/rowln_stamps.py
+__device__ unsigned long long g_rl_dbg[3][64];
+#define RL_STAMP(slot)                                                                                             \
+    do {                                                                                                           \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && rl_si + (slot) < 64)                                            \
+            g_rl_dbg[g.K == 384 ? 0 : (g.K == 1536 ? 1 : 2)][rl_si + (slot)] = wall_clock64();                     \
+    } while (0)
+#else
+#define RL_STAMP(slot) do {} while (0)
+#endif
+
 // LN_PLANES: LayerNorm output as activation planes (next GEMM's operand) or fp32 (final norm);
 // RES_TABLE: the residual row is row % res_mod of a [res_mod, 384] table (patch embed: cls / conv bias + pos)
 template <bool LN_PLANES, bool RES_TABLE>
@@ -97,7 +108,10 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
         const int lt = ld_tile < n_tiles ? ld_tile : n_tiles - 1;   // past the end: re-load, never consumed
         const unsigned sa = unsigned(lt) * unsigned(RM) * unsigned(g.lda) * 4u + unsigned(ld_kt) * 128u, sw = unsigned(ld_kt) * 128u;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) r0[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, sa + i * a64, 0);
+        // A rows are read exactly once per launch (a tile spans all 384 columns): sc0 + nt keeps the 150 - 600 MB stream
+        // from displacing x / xn, which the next kernels re-read (+0.8 % on the step; the same hint on the residual
+        // loads, the x stores or the xn stores costs 1 - 10 %: measured, left at the default policy)
+        for (int i = 0; i < 2; ++i) r0[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, sa + i * a64, 3);
 #pragma unroll
         for (int i = 0; i < 6; ++i) r0[2 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, sw + i * w64, 0);
         const int wrap = ++ld_kt == nk;
@@ -131,8 +145,10 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(g.res), 0, unsigned(RES_TABLE ? g.res_mod : g.M) * unsigned(g.ldres) * 4u, 0x00020000);
 
+    int rl_si = 0;   // stamp index (dev builds)
     auto epilogue = [&](int tile) {
         const int m0 = tile * RM;
+        RL_STAMP(1);
         // The lane coordinates are re-derived behind an opaque fence: every address below would otherwise be hoisted
         // out of the tile loop as a loop invariant (~40 registers held across the K-steps: spills in the mainloop).
         int l15 = threadIdx.x & 15, q4 = (threadIdx.x >> 4) & 3;
@@ -156,9 +172,11 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
                                     rres, rr * unsigned(g.ldres) * 4u + unsigned(col0) * 4u, ni * 64, 0));
                 acc[mi][ni] = r + acc[mi][ni] * gam + bia;
             }
-            __builtin_amdgcn_sched_barrier(0);   // at most one column block's residual rows in flight (register budget)
+            __builtin_amdgcn_sched_barrier(0);   // one column block's residual rows in flight (2, 3 or 6: no difference —
+                                                 // the phase runs at the memory system's speed, all CUs at once)
         }
         __builtin_amdgcn_sched_barrier(0);
+        RL_STAMP(2);
         // ---- 2. row means: lane -> quad of lanes -> the four column waves (LDS) ------------------------------------
         const int rl = wm * 64 + l15;   // row within the tile, + 16 mi
 #pragma unroll
@@ -177,6 +195,7 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
             mean[mi] = ((p[0] + p[RM]) + (p[2 * RM] + p[3 * RM])) * (1.0f / float(RN));
         }
         __builtin_amdgcn_sched_barrier(0);
+        RL_STAMP(3);
         // ---- 3. x to memory (the residual stream), then centre in place and take the second moment -----------------
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) {
@@ -205,6 +224,7 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
             rstd[mi] = 1.0f / sqrtf(var + g.ln_eps);
         }
         __builtin_amdgcn_sched_barrier(0);
+        RL_STAMP(4);
         float finite_probe = 0.f;   // a non-finite row (poisoned x) has a non-finite mean or rstd
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) finite_probe += __builtin_fabsf(mean[mi]) + rstd[mi];
@@ -237,6 +257,7 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
             pope_range_flag(g.range_flag, POPE_RANGE_LAYERNORM,
                             !(__builtin_fmaxf(amax[0], amax[1]) < POPE_F16_OVERFLOW) ||
                                 !(finite_probe < INFINITY));
+        RL_STAMP(5);
     };
 
     // prologue: item 0 -> LDS stage 0; item 1 in flight
@@ -246,6 +267,7 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
     __syncthreads();
     zero_acc();
     int tile = first, kt = 0;
+    RL_STAMP(0);
 
     auto item = [&](int s) {
         const _Float16* S = lds + (s & 1) * STAGE_H;
@@ -292,6 +314,8 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
             zero_acc();
             kt = 0;
             tile = tile_of(++ord);
+            rl_si += 8;
+            RL_STAMP(0);
         }
     };
     for (int s = 0; tile < n_tiles; ++s) item(s);
@@ -307,6 +331,12 @@ int launch_rowln(const GemmParams& g, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef RL_STAMPS
+extern "C" int pope_lab_rowln_stamps(unsigned long long* host192) {
+    return hipMemcpyFromSymbol(host192, HIP_SYMBOL(g_rl_dbg), sizeof(unsigned long long) * 192) == hipSuccess ? 0 : -1;
+}
+#endif
 
 bool pope_gemm_rowln_supported(const GemmParams& g) {
     return g.N == RN && g.ldc == RN && g.K >= 2 * RK && (g.K % RK) == 0 && g.lda == g.K && g.ldw == g.K && g.ldres == RN &&
