@@ -761,8 +761,9 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
                 split4(v * 8.0f, hi, lo);  // K_PLANES_ACT_SCALE
                 const int col = head * HD + c4;
                 _Float16* o = reinterpret_cast<_Float16*>(out) + (size_t(b) * N + qrow) * 2 * D + (col >> 5) * 64 + (col & 31);
-                *reinterpret_cast<f16x4*>(o) = hi;
-                *reinterpret_cast<f16x4*>(o + 32) = lo;
+                // written once, read once (by the proj GEMM, whose A loads carry the same hint): proj -2 %
+                __builtin_nontemporal_store(hi, reinterpret_cast<f16x4*>(o));
+                __builtin_nontemporal_store(lo, reinterpret_cast<f16x4*>(o + 32));
             } else {
                 *reinterpret_cast<f32x4*>(out + (size_t(b) * N + qrow) * D + head * HD + c4) = v;
             }
