@@ -297,8 +297,12 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
             // are loaded for almost a whole K-step — except across a tile seam: the epilogue needs those registers (with
             // them live it spills, and a spill reload drains vmcnt, i.e. waits for every load in flight), so the seam
             // load is issued after the epilogue and still has four column groups of MFMAs to arrive
+#ifndef RL_ABL_NOWRITE   // dev ablations (wrong results; scripts/ab_rowln.sh): what the staging costs a K-step
             if (ni == 4) write_stage((s + 1) & 1);
+#endif
+#ifndef RL_ABL_NOLOAD
             if (ni == 5 && kt + 1 != nk) load_next();
+#endif
 #pragma unroll
             for (int mi = 0; mi < NMI; ++mi) acc[mi][ni] = mfma16(wl[cur], ah[mi], acc[mi][ni]);
 #pragma unroll
