@@ -107,13 +107,17 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
     auto load_next = [&]() {
         const int lt = ld_tile < n_tiles ? ld_tile : n_tiles - 1;   // past the end: re-load, never consumed
         const unsigned sa = unsigned(lt) * unsigned(RM) * unsigned(g.lda) * 4u + unsigned(ld_kt) * 128u, sw = unsigned(ld_kt) * 128u;
-#pragma unroll
         // A rows are read exactly once per launch (a tile spans all 384 columns): sc0 + nt keeps the 150 - 600 MB stream
         // from displacing x / xn, which the next kernels re-read (+0.8 % on the step; the same hint on the residual
         // loads, the x stores or the xn stores costs 1 - 10 %: measured, left at the default policy)
+#ifndef RL_ABL_NOLOAD_A   // dev ablations (wrong results; scripts/ab_rowln.sh): which operand's loads cost the K-step what
+#pragma unroll
         for (int i = 0; i < 2; ++i) r0[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, sa + i * a64, 3);
+#endif
+#ifndef RL_ABL_NOLOAD_W
 #pragma unroll
         for (int i = 0; i < 6; ++i) r0[2 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, sw + i * w64, 0);
+#endif
         const int wrap = ++ld_kt == nk;
         ld_kt = pope_uniform_select(wrap, 0, ld_kt);
         ld_ord += wrap;
