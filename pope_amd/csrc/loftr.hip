@@ -69,12 +69,11 @@ __global__ __launch_bounds__(256) void linattn_reduce_kernel(const float* __rest
 
 // KV / Ksum = sum of the chunk partials, in chunk order.  kvf: [n * H, D * D + D]
 __global__ __launch_bounds__(256) void linattn_finish_kernel(const float* __restrict__ part, int chunks, int per, float* __restrict__ kvf) {
-    const int nh = blockIdx.x;
-    for (int i = threadIdx.x; i < per; i += 256) {
-        float s = 0.f;
-        for (int c = 0; c < chunks; ++c) s += part[(size_t(nh) * chunks + c) * per + i];
-        kvf[size_t(nh) * per + i] = s;
-    }
+    const int nh = blockIdx.x, i = blockIdx.y * 256 + threadIdx.x;   // one value per thread: (n H) x ceil(per / 256) blocks
+    if (i >= per) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(size_t(nh) * chunks + c) * per + i];
+    kvf[size_t(nh) * per + i] = s;
 }
 
 // msg[l, h, v] = (sum_d Q[l,h,d] KV[h][d][v]) * (1 / (sum_d Q[l,h,d] Ksum[h][d] + eps)) * S,  Q = elu(q) + 1.
@@ -241,7 +240,7 @@ int pope_launch_loftr_layer(const LoftrLayerParams& p, hipStream_t stream) {
     // 3. per-head state, 4. message
     if (D == 32) hipLaunchKernelGGL(linattn_reduce_kernel<32>, dim3(p.n * H, chunks), dim3(256), 0, stream, kv, p.S, C, H, 0.f, part, chunks);
     else hipLaunchKernelGGL(linattn_reduce_kernel<16>, dim3(p.n * H, chunks), dim3(256), 0, stream, kv, p.S, C, H, 0.f, part, chunks);
-    hipLaunchKernelGGL(linattn_finish_kernel, dim3(p.n * H), dim3(256), 0, stream, part, chunks, per, kvf);
+    hipLaunchKernelGGL(linattn_finish_kernel, dim3(p.n * H, (per + 255) / 256), dim3(256), 0, stream, part, chunks, per, kvf);
     const int rpb = 16;
     if (D == 32) hipLaunchKernelGGL(linattn_apply_kernel<32>, dim3(p.n, (p.L + rpb - 1) / rpb), dim3(256), 0, stream, q, kvf, p.L, C, H, p.S, 1e-6f, msg, rpb);
     else hipLaunchKernelGGL(linattn_apply_kernel<16>, dim3(p.n, (p.L + rpb - 1) / rpb), dim3(256), 0, stream, q, kvf, p.L, C, H, p.S, 1e-6f, msg, rpb);
