@@ -132,6 +132,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(pope_amd has no fallback path)")
+        # torch FIRST: it ships its own HIP runtime (torch/lib/libamdhip64.so).  If libpope_hip.so is the first to
+        # pull in a libamdhip64 (the system one), the process ends up with two runtimes and every launch of ours on a
+        # torch stream fails — `build()` followed by `smoke()` in one process did exactly that
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol

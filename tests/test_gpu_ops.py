@@ -341,3 +341,16 @@ def test_layernorm_planes_and_split(dev, hip_lib):
     sp = torch.empty(1000, 2, 2, 32, dtype=torch.float16, device=dev)
     assert hip_lib.pope_split_planes_f32(P(src.to(dev)), P(sp), 1000, 64, _lib.PLANES_W_SCALE, None, st) == 0
     assert torch.equal(sp.cpu(), _lib.to_planes(src, _lib.PLANES_W_SCALE))
+
+
+def test_build_then_smoke_in_one_process(dev):
+    """The driver's two entry points back to back in ONE fresh process: build() loads libpope_hip.so before anything has
+    imported torch.  The library must still end up on torch's HIP runtime (pope_amd/_lib.py:lib imports torch first;
+    with the system libamdhip64 loaded first every launch on a torch stream fails)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "smoke ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
