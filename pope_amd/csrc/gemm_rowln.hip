@@ -301,7 +301,17 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
             // are loaded for almost a whole K-step — except across a tile seam: the epilogue needs those registers (with
             // them live it spills, and a spill reload drains vmcnt, i.e. waits for every load in flight), so the seam
             // load is issued after the epilogue and still has four column groups of MFMAs to arrive
-#ifndef RL_ABL_NOWRITE   // dev ablations (wrong results; scripts/ab_rowln.sh): what the staging costs a K-step
+#if defined(RL_ABL_SPREADW)   // dev ablation: the eight LDS stores spread over the six column groups instead of one burst
+            {
+                constexpr int first_piece[7] = {0, 1, 3, 4, 6, 7, 8};
+                _Float16* Sw = lds + ((s + 1) & 1) * STAGE_H + wr_off;
+#pragma unroll
+                for (int q = first_piece[ni]; q < first_piece[ni + 1]; ++q) {
+                    if (q < 2) *reinterpret_cast<u32x4*>(Sw + 64 * q * ROWB) = r0[q];
+                    else *reinterpret_cast<u32x4*>(Sw + (RM + 64 * (q - 2)) * ROWB) = r0[q];
+                }
+            }
+#elif !defined(RL_ABL_NOWRITE)   // dev ablations (wrong results; scripts/ab_rowln.sh): what the staging costs a K-step
             if (ni == 4) write_stage((s + 1) & 1);
 #endif
 #ifndef RL_ABL_NOLOAD
