@@ -264,6 +264,9 @@ class DinoVisionTransformer(nn.Module):
         ntok = 1 + (H // p) * (W // p)
         dim = self.embed_dim
         precision = precision or self.precision
+        if B == 0:   # an empty batch is legal in the reference (every op is a no-op on it): empty outputs, no launch
+            e = torch.empty(0, ntok, dim, device=x.device, dtype=torch.float32)
+            return e, (out_norm if out_norm is not None else e.clone()), [e.clone() for _ in taps]
         # The kernels address a launch sequence's activations through 32-bit byte offsets: larger batches are run as
         # several sequences writing into slices of the same outputs (identical results: images are independent).
         widest = max(4 * dim, int(self.blocks[0].mlp.fc1.weight.shape[0]))

@@ -62,6 +62,13 @@ def dense_match(feat0, feat1, hw0_c, hw1_c, hw0_i, thr=0.2, border_rm=2, tempera
     h1, w1 = int(hw1_c[0]), int(hw1_c[1])
     assert feat1.shape[0] == n and feat1.shape[2] == Cc and L == h0 * w0 and S == h1 * w1
     dev = feat0.device
+    if n == 0:   # an empty batch: what torch.where gives the reference on a [0, L, S] mask
+        el, ef = torch.empty(0, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.float32, device=dev)
+        out = {"b_ids": el, "i_ids": el.clone(), "j_ids": el.clone(), "gt_mask": torch.empty(0, dtype=torch.bool, device=dev),
+               "m_bids": el.clone(), "mkpts0_c": ef.reshape(0, 2), "mkpts1_c": ef.reshape(0, 2).clone(), "mconf": ef.clone(),
+               "counts": torch.empty(0, dtype=torch.int32),
+               "conf_matrix": torch.empty(0, L, S, dtype=torch.float32, device=dev) if want_conf else None}
+        return out
     lib = _lib.lib()
     precision = precision or DEFAULT_PRECISION
     if Cc % 32 or Cc < 64:
