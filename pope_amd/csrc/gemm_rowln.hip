@@ -150,8 +150,15 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
         const_cast<float*>(g.res), 0, unsigned(RES_TABLE ? g.res_mod : g.M) * unsigned(g.ldres) * 4u, 0x00020000);
 
     int rl_si = 0;   // stamp index (dev builds)
-    auto epilogue = [&](int tile) {
+    auto epilogue = [&](int tile, int free_stage) {
         const int m0 = tile * RM;
+        // per-wave transposition buffer in the LDS stage the K loop has just finished with (the other stage already holds
+        // the next tile's first K-step): 16 rows x 96 columns of this wave at a time, 400-byte pitch (conflict-free
+        // 16-byte pieces from the accumulator layout), read back as whole 128-byte lines: 8 lanes per line
+        float* wreg = reinterpret_cast<float*>(lds + free_stage * STAGE_H) + (threadIdx.x >> 6) * 1600;
+        int elane = threadIdx.x & 63;
+        asm volatile("" : "+v"(elane));
+        const int epiece = elane & 7;
         RL_STAMP(1);
         // The lane coordinates are re-derived behind an opaque fence: every address below would otherwise be hoisted
         // out of the tile loop as a loop invariant (~40 registers held across the K-steps: spills in the mainloop).
@@ -203,10 +210,17 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
         // ---- 3. x to memory (the residual stream), then centre in place and take the second moment -----------------
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) {
-            const unsigned off = unsigned(m0 + wm * 64 + mi * 16 + l15) * unsigned(RN) * 4u + unsigned(wn * 96 + 4 * q4) * 4u;
 #pragma unroll
-            for (int ni = 0; ni < 6; ++ni)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mi][ni]), rx, off, ni * 64, 0);
+            for (int ni = 0; ni < 6; ++ni) *reinterpret_cast<f32x4*>(&wreg[l15 * 100 + ni * 16 + 4 * q4]) = acc[mi][ni];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {   // 48 lines of 128 bytes: 16 rows x 3
+                const int L = t * 8 + (elane >> 3), row = (L * 43) >> 7, ln = L - 3 * row;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&wreg[row * 100 + ln * 32 + epiece * 4]);
+                const unsigned off = unsigned(m0 + wm * 64 + mi * 16 + row) * unsigned(RN) * 4u + unsigned(wn * 96 + ln * 32 + epiece * 4) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rx, off, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) {
@@ -235,27 +249,35 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
         // ---- 4. xn = (x - mean) * rstd * w + b -> planes (or fp32) ---------------------------------------------------
         f32x2 amax = {0.f, 0.f};
 #pragma unroll
-        for (int ni = 0; ni < 6; ++ni) {
-            const f32x4 lw = *reinterpret_cast<const f32x4*>(ctab + 2 * RN + col0 + 16 * ni);
-            const f32x4 lb = *reinterpret_cast<const f32x4*>(ctab + 3 * RN + col0 + 16 * ni);
-            const int col = col0 + 16 * ni;
+        for (int mi = 0; mi < NMI; ++mi) {
 #pragma unroll
-            for (int mi = 0; mi < NMI; ++mi) {
-                const unsigned rowb = unsigned(m0 + wm * 64 + mi * 16 + l15) * unsigned(RN) * 4u;   // fp32 and planes rows: same pitch
+            for (int ni = 0; ni < 6; ++ni) {
+                const f32x4 lw = *reinterpret_cast<const f32x4*>(ctab + 2 * RN + col0 + 16 * ni);
+                const f32x4 lb = *reinterpret_cast<const f32x4*>(ctab + 3 * RN + col0 + 16 * ni);
                 const f32x4 y = acc[mi][ni] * rstd[mi] * lw + lb;
                 if constexpr (LN_PLANES) {
                     const f32x4 ys = y * A_SCALE;
                     pope_amax4x2(amax, ys);
                     f16x4 hi, lo;
                     pope_split4(ys, hi, lo);
-                    const unsigned o = rowb + unsigned((col >> 5) * 128 + (col & 31) * 2);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rln, o, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rln, o + 64u, 0, 0);
+                    const int c = ni * 16 + 4 * q4;   // column within the wave's 96 = three planes chunks of 128 bytes
+                    _Float16* hp = reinterpret_cast<_Float16*>(wreg) + l15 * 200 + (c >> 5) * 64 + (c & 31);
+                    *reinterpret_cast<f16x4*>(hp) = hi;
+                    *reinterpret_cast<f16x4*>(hp + 32) = lo;
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rln, rowb + unsigned(col) * 4u, 0, 0);
+                    *reinterpret_cast<f32x4*>(&wreg[l15 * 100 + ni * 16 + 4 * q4]) = y;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);   // one column block at a time (register budget)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int L = t * 8 + (elane >> 3), row = (L * 43) >> 7, ln = L - 3 * row;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&wreg[row * 100 + ln * 32 + epiece * 4]);
+                // planes rows and fp32 rows have the same pitch, and the wave's 96 columns are 384 bytes of either
+                const unsigned off = unsigned(m0 + wm * 64 + mi * 16 + row) * unsigned(RN) * 4u + unsigned(wn * 96 + ln * 32 + epiece * 4) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rln, off, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         if constexpr (LN_PLANES)   // a non-finite row (poisoned x) has a non-finite mean or rstd; fmax ignores NaN
             pope_range_flag(g.range_flag, POPE_RANGE_LAYERNORM,
@@ -327,7 +349,8 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
         }
         __syncthreads();  // stage (s+1)&1 is published, stage s&1 is free
         if (++kt == nk) {
-            epilogue(tile);
+            epilogue(tile, s & 1);
+            __syncthreads();   // the next K-step stores into the stage the slower waves may still be transposing through
             load_next();   // the K-step after the one already in LDS
             zero_acc();
             kt = 0;
