@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define POPE_ABI_VERSION 5
+#define POPE_ABI_VERSION 6
 
 enum {
     POPE_EPI_BIAS = 0,        /* C = A.W^T + bias                         nn.Linear                     */
@@ -275,6 +275,48 @@ int pope_fine_preprocess_f32(const float* feat_f0, const long long* strides0_hos
  * (scale_px = hw0_i[0] / hw0_f[0]).  win0, win1: [M, Wn*Wn, C] fp32 (the fine transformer's outputs). */
 int pope_fine_match_f32(const float* win0, const float* win1, int M, int Wn, int C, const float* mkpts1_c,
                         float scale_px, float* expec_f, float* mkpts1_f, void* stream);
+
+/* ---- SAM image encoder (BASELINE config 5) --------------------------------------------------- */
+
+/* ImageEncoderViT.forward — segment_anything/segment_anything/modeling/image_encoder.py:107-118 as build_sam.py:66-79
+ * configures it (LayerNorm eps 1e-6, qkv bias, absolute + decomposed relative position terms, window attention with
+ * `window` x `window` windows except in the blocks marked global, MLP ratio = hidden / dim, neck 1x1 conv ->
+ * LayerNorm2d -> 3x3 conv -> LayerNorm2d).  image[B,3,img,img] fp32 (already normalised and padded by the caller,
+ * sam.py preprocess) -> out[B,out_chans,g,g] fp32, g = img / patch.  head_dim = dim / heads must be 64 (ViT-B/L) or
+ * 80 (ViT-H); dim % 128 == 0; out_chans % 256 == 0; patch % 8 == 0.  f16x3 arithmetic throughout (fp32 operands as
+ * hi + lo f16 planes, three MFMAs per product, fp32 accumulate, fp32 softmax / LayerNorm / GELU / residual stream).
+ * Weights: `*_wp` = weight planes (pope_split_planes_f32, scale 256) of the torch [out, in] matrices —
+ * patch_wp[dim, 3 patch^2] = proj.weight.reshape(dim, -1); neck0_wp[out_chans, dim]; neck2_wp[out_chans, 9 out_chans]
+ * with the taps in (ky, kx, channel) order = weight.permute(0, 2, 3, 1).reshape(out_chans, -1).  pos[g*g, dim] or NULL.
+ * rel_h / rel_w: the tables get_rel_pos returns (image_encoder.py:288-316), R[q][k][head_dim] fp32 with q, k < window
+ * (window blocks) or < g (global blocks); the bias q.Rh + q.Rw is folded into the score product (sam.hip).
+ * ones[dim] = 1.0f.  blocks_host: HOST array [depth] of device pointers.  Optional taps as pope_vit_forward_f32
+ * (tap_out_host[t][B*g*g, dim] fp32 = output of block tap_blocks_host[t]). */
+typedef struct pope_sam_block_weights {
+    const float *norm1_w, *norm1_b;
+    const void* qkv_wp; const float* qkv_b;
+    const void* proj_wp; const float* proj_b;
+    const float *rel_h, *rel_w;
+    const float *norm2_w, *norm2_b;
+    const void* fc1_wp; const float* fc1_b;
+    const void* fc2_wp; const float* fc2_b;
+    int global_attn;
+} pope_sam_block_weights;
+typedef struct pope_sam_encoder_weights {
+    int img, patch, dim, depth, heads, hidden, out_chans, window;
+    const void* patch_wp; const float* patch_b;
+    const float* pos;
+    const float* ones;
+    const pope_sam_block_weights* blocks_host;
+    const void* neck0_wp;
+    const float *neck1_w, *neck1_b;
+    const void* neck2_wp;
+    const float *neck3_w, *neck3_b;
+} pope_sam_encoder_weights;
+size_t pope_sam_encoder_workspace_bytes(const pope_sam_encoder_weights* w_host, int B);
+int pope_sam_encoder_forward_f32(const pope_sam_encoder_weights* w_host, const float* image, int B, float* out,
+                                 int n_taps, const int* tap_blocks_host, float* const* tap_out_host,
+                                 void* workspace, size_t workspace_bytes, unsigned* range_flag, void* stream);
 
 /* ---- caller-side preprocessing, batched ------------------------------------------------- */
 

@@ -268,6 +268,75 @@ def gen_vit_archs():
         np.savez(os.path.join(OUT, name + ".npz"), **fx)
 
 
+SAM_CASES = {
+    # name: dim, depth, heads, img, window, global blocks, batch, output stride
+    "sam_hd80_256": (640, 4, 8, 256, 14, (1, 3), 2, 1),       # head_dim 80 (ViT-H's), grid 16 -> windows padded 16 -> 28
+    "sam_hd64_224": (256, 2, 4, 224, 14, (1,), 1, 1),         # head_dim 64 (ViT-B/L's), grid 14 = one exact window
+    "sam_vit_h_1024": (1280, 32, 16, 1024, 14, (7, 15, 23, 31), 1, 4),   # build_sam.py:13-21 at full size
+}
+
+
+def load_reference_sam_encoder():
+    """The reference's `ImageEncoderViT`, loaded by file path under a synthetic package: the real package __init__ pulls
+    torchvision / cv2, which this image lacks; image_encoder.py itself needs torch only."""
+    import types
+    base = os.path.join(REF, "segment_anything/segment_anything/modeling")
+    pkg = types.ModuleType("ref_sam_modeling")
+    pkg.__path__ = [base]
+    sys.modules["ref_sam_modeling"] = pkg
+    mods = {}
+    for name in ("common", "image_encoder"):
+        spec = importlib.util.spec_from_file_location(f"ref_sam_modeling.{name}", os.path.join(base, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = mod
+        spec.loader.exec_module(mod)
+        mods[name] = mod
+    return mods["image_encoder"].ImageEncoderViT
+
+
+def gen_sam_encoder(only=None):
+    """BASELINE config 5, SAM half: ImageEncoderViT as build_sam.py:66-79 configures it, seeded
+    synthetic weights, seeded input; the oracle restatement is checked against the reference's own module first."""
+    from functools import partial
+    from oracle import sam_encoder_ref
+    Enc = load_reference_sam_encoder()
+    for name, (dim, depth, heads, img, window, gidx, B, stride) in SAM_CASES.items():
+        if only and name not in only:
+            continue
+        sd = synth.synthetic_sam_encoder_state_dict(seed=0, dim=dim, depth=depth, heads=heads, grid=img // 16, window=window,
+                                                    global_idx=gidx)
+        m = Enc(depth=depth, embed_dim=dim, img_size=img, mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+                num_heads=heads, patch_size=16, qkv_bias=True, use_rel_pos=True, global_attn_indexes=list(gidx),
+                window_size=window, out_chans=256)
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        x = synth.synthetic_images(B, img, img, seed=11)
+        tap_blocks = sorted({0, gidx[0], depth - 1})
+        ref_taps = {}
+        hooks = [m.blocks[i].register_forward_hook(lambda mod, a, o, i=i: ref_taps.__setitem__(i, o.detach())) for i in tap_blocks]
+        with torch.no_grad():
+            out = m(x)
+        for h in hooks:
+            h.remove()
+        del m
+        taps = {i: None for i in tap_blocks}
+        with torch.no_grad():
+            mine = sam_encoder_ref.forward(sd, x, heads, window, gidx, taps)
+        d = {"out": maxdiff(out, mine)}
+        for i in tap_blocks:
+            d[f"blk{i}"] = maxdiff(ref_taps[i], taps[i])
+        print(name, "oracle-vs-reference max abs diff:", {k: f"{v:.2e}" for k, v in d.items()},
+              "| |out| max", float(out.abs().max()), "|x| max", float(ref_taps[depth - 1].abs().max()))
+        assert max(d.values()) <= 2e-4, d
+        fx = {"weights_seed": 0, "arch": np.array([dim, depth, heads, img, window]), "global_idx": np.array(gidx),
+              "weights_digest": sd_digest(sd), "input_seed": 11, "batch": B, "stride": stride,
+              "input_digest": np.array([float(x.double().sum()), float(x.double().abs().sum())]),
+              "tap_blocks": np.array(tap_blocks), "out": out[:, :, ::stride, ::stride].numpy()}
+        for i in tap_blocks:
+            fx[f"blk{i}"] = ref_taps[i][:, ::max(2, stride), ::max(2, stride), ::2].numpy()
+        np.savez(os.path.join(OUT, name + ".npz"), **fx)
+
+
 def sd_digest(sd):
     return np.array([float(sd[k].double().sum()) for k in sorted(sd)], np.float64)
 
@@ -299,6 +368,8 @@ def main():
         return gen_pair_lists()
     if "--only-archs" in sys.argv:
         return gen_vit_archs()
+    if "--only-sam" in sys.argv:   # optionally followed by case names
+        return gen_sam_encoder([a for a in sys.argv[sys.argv.index("--only-sam") + 1:] if not a.startswith("-")])
     if "--only-loftr" in sys.argv:
         return gen_loftr()
     if "--only-driver" in sys.argv:
@@ -414,6 +485,7 @@ def main():
     gen_driver()
     gen_pair_lists()
     gen_vit_archs()
+    gen_sam_encoder()
     print("golden fixtures written to", OUT)
 
 

@@ -38,6 +38,18 @@ class ResnetFpnWeights(C.Structure):
     _fields_ = [("w", C.c_void_p * 22), ("b", C.c_void_p * 22)]
 
 
+class SamBlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm1_w", "norm1_b", "qkv_wp", "qkv_b", "proj_wp", "proj_b", "rel_h", "rel_w",
+                                           "norm2_w", "norm2_b", "fc1_wp", "fc1_b", "fc2_wp", "fc2_b")] + [("global_attn", C.c_int)]
+
+
+class SamEncoderWeights(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("img", "patch", "dim", "depth", "heads", "hidden", "out_chans", "window")] + [
+        ("patch_wp", C.c_void_p), ("patch_b", C.c_void_p), ("pos", C.c_void_p), ("ones", C.c_void_p),
+        ("blocks_host", C.POINTER(SamBlockWeights)), ("neck0_wp", C.c_void_p), ("neck1_w", C.c_void_p), ("neck1_b", C.c_void_p),
+        ("neck2_wp", C.c_void_p), ("neck3_w", C.c_void_p), ("neck3_b", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/pope_hip.h
 PREC_F32_MFMA, PREC_F16X3 = 0, 1
 PLANES_ACT_SCALE, PLANES_W_SCALE = 8.0, 256.0
@@ -95,6 +107,9 @@ PROTOTYPES = {
                                  + [C.c_void_p] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pope_fine_match_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "pope_sam_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(SamEncoderWeights), C.c_int]),
+    "pope_sam_encoder_forward_f32": (C.c_int, [C.POINTER(SamEncoderWeights), C.c_void_p, C.c_int, C.c_void_p, C.c_int, c_int_p,
+                                               C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pope_preprocess_u8_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3
                                + [C.c_int] * 7 + [c_float_p, c_float_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pope_crop_normalize_u8_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [c_float_p, c_float_p, C.c_void_p, C.c_void_p]),
@@ -141,7 +156,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.pope_abi_version() != 5:
+        if handle.pope_abi_version() != 6:
             raise RuntimeError("libpope_hip.so ABI version mismatch")
         _lib = handle
     return _lib

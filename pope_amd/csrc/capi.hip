@@ -559,6 +559,45 @@ int pope_fine_match_f32(const float* win0, const float* win1, int M, int Wn, int
     return pope_launch_fine_match(win0, win1, M, Wn, C, mkpts1_c, scale_px, expec_f, mkpts1_f, static_cast<hipStream_t>(stream));
 }
 
+static bool sam_params(const pope_sam_encoder_weights* w, int B, SamEncParams& q, SamBlockParams* blocks) {
+    if (!w || !w->blocks_host || w->depth <= 0 || w->depth > 64) return false;
+    q = SamEncParams{};
+    q.B = B; q.img = w->img; q.patch = w->patch; q.dim = w->dim; q.depth = w->depth; q.heads = w->heads; q.hidden = w->hidden;
+    q.out_chans = w->out_chans; q.window = w->window;
+    q.patch_wp = w->patch_wp; q.patch_b = w->patch_b; q.pos = w->pos; q.ones = w->ones;
+    q.neck0_wp = w->neck0_wp; q.neck1_w = w->neck1_w; q.neck1_b = w->neck1_b; q.neck2_wp = w->neck2_wp;
+    q.neck3_w = w->neck3_w; q.neck3_b = w->neck3_b;
+    for (int i = 0; blocks && i < w->depth; ++i) {
+        const pope_sam_block_weights& s = w->blocks_host[i];
+        SamBlockParams& d = blocks[i];
+        d.norm1_w = s.norm1_w; d.norm1_b = s.norm1_b; d.qkv_wp = s.qkv_wp; d.qkv_b = s.qkv_b; d.proj_wp = s.proj_wp;
+        d.proj_b = s.proj_b; d.rel_h = s.rel_h; d.rel_w = s.rel_w; d.norm2_w = s.norm2_w; d.norm2_b = s.norm2_b;
+        d.fc1_wp = s.fc1_wp; d.fc1_b = s.fc1_b; d.fc2_wp = s.fc2_wp; d.fc2_b = s.fc2_b; d.global = s.global_attn;
+    }
+    q.blocks = blocks;
+    return true;
+}
+
+size_t pope_sam_encoder_workspace_bytes(const pope_sam_encoder_weights* w, int B) {
+    SamEncParams q;
+    if (!sam_params(w, B, q, nullptr)) return 0;
+    return pope_sam_encoder_workspace(q);
+}
+
+int pope_sam_encoder_forward_f32(const pope_sam_encoder_weights* w, const float* image, int B, float* out, int n_taps,
+                                 const int* tap_blocks_host, float* const* tap_out_host, void* workspace, size_t workspace_bytes,
+                                 unsigned* range_flag, void* stream) {
+    StreamDevice on_device(stream);
+    SamEncParams q;
+    SamBlockParams blocks[64];
+    if (!sam_params(w, B, q, blocks)) return POPE_ERR_ARG;
+    if (n_taps < 0 || (n_taps > 0 && (!tap_blocks_host || !tap_out_host))) return POPE_ERR_ARG;
+    q.image = image; q.out = out;
+    q.n_taps = n_taps; q.tap_blocks = tap_blocks_host; q.tap_out = tap_out_host;
+    q.ws = workspace; q.ws_bytes = workspace_bytes; q.range_flag = range_flag;
+    return pope_launch_sam_encoder(q, static_cast<hipStream_t>(stream));
+}
+
 int pope_preprocess_u8_f32(const unsigned char* img_hwc, int P, int Hin, int Win, const int* hstart, const int* hcount,
                            const int* hk, int kh, const int* vstart, const int* vcount, const int* vk, int kv, int top, int left,
                            int ch, int cw, int row0, int nrows, const float* mean_host, const float* std_host, float* out,

@@ -216,3 +216,35 @@ int pope_launch_fine_match(const float* win0, const float* win1, int M, int Wn, 
                            float* expec, float* mkpts1_f, hipStream_t stream);
 size_t pope_loftr_layer_workspace(int n, int L, int S, int C, int H);
 int pope_launch_loftr_layer(const LoftrLayerParams& p, hipStream_t stream);
+
+// SAM image encoder (sam.hip; segment_anything/segment_anything/modeling/image_encoder.py:17-118).  Weight planes: scale
+// K_PLANES_W_SCALE, torch Linear layout [out, in]; every pointer is a device pointer except `blocks`, `tap_blocks`, `tap_out`.
+struct SamBlockParams {
+    const float *norm1_w, *norm1_b;
+    const void* qkv_wp; const float* qkv_b;      // [3 dim, dim], [3 dim]
+    const void* proj_wp; const float* proj_b;    // [dim, dim], [dim]
+    const float *rel_h, *rel_w;                  // gathered tables R[q][k][head_dim] (get_rel_pos, image_encoder.py:288-316): [s, s, hd]
+                                                 // with s = window (window blocks) or grid (global blocks)
+    const float *norm2_w, *norm2_b;
+    const void* fc1_wp; const float* fc1_b;      // [hidden, dim]
+    const void* fc2_wp; const float* fc2_b;      // [dim, hidden]
+    int global;                                  // 1: global attention (window_size 0, image_encoder.py:77)
+};
+struct SamEncParams {
+    const float* image;   // [B, 3, img, img] fp32
+    float* out;           // [B, out_chans, g, g] fp32, g = img / patch
+    int B, img, patch, dim, depth, heads, hidden, out_chans, window;
+    const void* patch_wp; const float* patch_b;   // [dim, 3 patch^2], [dim]
+    const float* pos;                             // [g g, dim] or null (use_abs_pos = False)
+    const float* ones;                            // [dim] of 1.0f (no LayerScale in this ViT)
+    const SamBlockParams* blocks;                 // host array [depth]
+    const void* neck0_wp;                         // [out_chans, dim]
+    const float *neck1_w, *neck1_b;
+    const void* neck2_wp;                         // [out_chans, 9 out_chans], taps (ky, kx, channel)
+    const float *neck3_w, *neck3_b;
+    int n_taps; const int* tap_blocks; float* const* tap_out;   // optional block outputs [B g g, dim] fp32
+    void* ws; size_t ws_bytes;
+    unsigned* range_flag;
+};
+size_t pope_sam_encoder_workspace(const SamEncParams& q);
+int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream);

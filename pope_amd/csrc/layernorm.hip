@@ -290,8 +290,8 @@ int pope_launch_layernorm_planes(const float* x, int ldx, const float* w, const 
                            K_PLANES_ACT_SCALE, flag);                                                     \
         break;
     switch (dim / 128) {
-        POPE_LNP_CASE(1) POPE_LNP_CASE(2) POPE_LNP_CASE(3) POPE_LNP_CASE(4) POPE_LNP_CASE(6) POPE_LNP_CASE(8)
-        POPE_LNP_CASE(12) POPE_LNP_CASE(16)
+        POPE_LNP_CASE(1) POPE_LNP_CASE(2) POPE_LNP_CASE(3) POPE_LNP_CASE(4) POPE_LNP_CASE(5) POPE_LNP_CASE(6) POPE_LNP_CASE(8)
+        POPE_LNP_CASE(10) POPE_LNP_CASE(12) POPE_LNP_CASE(16)   // 5, 10: the SAM ViT-H width 1280 and its test twin 640
         default: return POPE_ERR_ARG;
     }
 #undef POPE_LNP_CASE

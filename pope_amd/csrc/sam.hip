@@ -1,0 +1,648 @@
+// SAM image encoder (segment_anything/segment_anything/modeling/image_encoder.py:17-118: ViT-B/L/H with 14x14 window
+// attention, four global blocks, decomposed relative position terms, and the 1x1 / 3x3 convolution neck) on the f16x3
+// planes GEMMs of the DINOv2 path.  BASELINE config 5 / SURVEY.md §8 f-3.
+//
+// What is new here is the attention.  softmax(scale q.k^T + q.Rh[qh,kh] + q.Rw[qw,kw]) (image_encoder.py:225-231,
+// 325-358) is evaluated as ONE matrix product per (window, head) by widening the operands:
+//     Q'[n] = [ scale q[n] | q[n].Rh[qh(n), 0..KH) | q[n].Rw[qw(n), 0..KW) ]      (all times log2 e)
+//     K'[m] = [ k[m]       | onehot(kh(m))          | onehot(kw(m))          ]
+// so Q'.K'^T is the biased score and the flash kernel needs no bias path at all: the relative-position terms ride on
+// the matrix cores (K' one-hot columns are exact in f16 and have no lo plane: 2 MFMAs per step there instead of 3).
+// `sam_attn_prep_kernel` builds Q', K', V as f16 hi/lo planes per (window, head) straight from the QKV GEMM's fp32
+// output — it also does the window partition, and the zero-padded tokens of the bottom / right windows
+// (image_encoder.py:251-254, padded AFTER norm1) get k = v = the qkv bias, exactly what Linear(0) gives the reference.
+// `sam_attn_kernel` is the single-stage f16x3 flash kernel of attention_f16x3.hip re-cut for 32-key tiles, a
+// K depth of 16 * NSTEP and 32 * DVT value columns; its epilogue un-partitions (drops the pad queries) and writes the
+// activation planes of the proj GEMM.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr float L2E = 1.44269504088896340736f;
+constexpr float A_SCALE = K_PLANES_ACT_SCALE;
+
+inline int grid_for(long long total, int per_block = 256) {
+    long long b = (total + per_block - 1) / per_block;
+    const long long cap = 64ll * pope_cu_count();
+    return int(b < 1 ? 1 : (b > cap ? cap : b));
+}
+inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
+
+__device__ __forceinline__ f16x8 cat(f16x4 a, f16x4 b) { return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+__device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// ---- patch embed operand: image [B, 3, S, S] -> activation planes [B * g * g, 3 * P * P], k = (c, ky, kx) as
+// Conv2d's weight.reshape(dim, -1) (image_encoder.py:385-393); P % 8 == 0
+__global__ __launch_bounds__(256) void sam_im2col_kernel(const float* __restrict__ img, _Float16* __restrict__ out, int B, int S,
+                                                         int P, unsigned* range_flag) {
+    const int g = S / P, K = 3 * P * P, pieces = K / 8;
+    const long long total = (long long)B * g * g * pieces;
+    float amax = 0.f;
+    for (long long id = blockIdx.x * 256ll + threadIdx.x; id < total; id += 256ll * gridDim.x) {
+        const int pc = int(id % pieces);
+        const long long row = id / pieces;
+        const int px = int(row % g), py = int((row / g) % g), b = int(row / ((long long)g * g));
+        const int k = pc * 8, c = k / (P * P), ky = (k - c * P * P) / P, kx = k - c * P * P - ky * P;
+        const float* src = img + (((size_t)b * 3 + c) * S + (py * P + ky)) * S + px * P + kx;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+        amax = pope_amax4(pope_amax4(amax, v0), v1);
+        const float s8 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+        if (!(s8 == s8)) amax = INFINITY;   // NaN (fmax drops it)
+        f16x4 h0, l0, h1, l1;
+        pope_split4(v0 * A_SCALE, h0, l0);
+        pope_split4(v1 * A_SCALE, h1, l1);
+        _Float16* o = out + (size_t)row * 2 * K + (k >> 5) * 64 + (k & 31);
+        *reinterpret_cast<f16x8*>(o) = cat(h0, h1);
+        *reinterpret_cast<f16x8*>(o + 32) = cat(l0, l1);
+    }
+    pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax * A_SCALE < POPE_F16_OVERFLOW));
+}
+
+// ---- attention geometry (host and device) -----------------------------------------------------------------------
+struct AttnGeom {
+    int B, g;             // images, token grid (g x g)
+    int ws, nw;           // window side and windows per axis (global block: ws = g, nw = 1)
+    int heads, hd, dim;   // hd = 64 or 80
+    int Nq, Npad;         // tokens per window (ws * ws) and rounded up to the 32-key tile
+    int DQ, HDP, DV;      // score depth (16 * NSTEP >= hd + 2 ws), lo-plane depth (= hd), value columns (32 * DVT)
+};
+
+// Q' / K' / V planes of one block's attention, 16 tokens of one (window, head) per workgroup.
+//   Qp [G][Npad][DQ hi | DQ lo], Kp [G][Npad][DQ hi | hd lo], Vp [G][Npad][DV hi | DV lo]   (halves; G = B nw^2 heads)
+// Rh / Rw: [ws][ws][hd] fp32, the gathered tables get_rel_pos returns (image_encoder.py:288-316; host, once per model).
+__global__ __launch_bounds__(256) void sam_attn_prep_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                            const float* __restrict__ Rh, const float* __restrict__ Rw,
+                                                            _Float16* __restrict__ Qp, _Float16* __restrict__ Kp,
+                                                            _Float16* __restrict__ Vp, AttnGeom a, unsigned* range_flag) {
+    __shared__ __attribute__((aligned(16))) float sq[3][16][80];
+    const int tid = threadIdx.x;
+    const int grp = blockIdx.y, n0 = blockIdx.x * 16;
+    const int head = grp % a.heads, wb = grp / a.heads;
+    const int win = wb % (a.nw * a.nw), b = wb / (a.nw * a.nw);
+    const int wy = win / a.nw, wx = win - wy * a.nw;
+    const int hd = a.hd;
+    for (int idx = tid; idx < 16 * 3 * hd; idx += 256) {
+        const int t = idx / (3 * hd), rem = idx - t * 3 * hd, which = rem / hd, c = rem - which * hd;
+        const int n = n0 + t;
+        float v = 0.f;
+        if (n < a.Nq) {
+            const int y = wy * a.ws + n / a.ws, x = wx * a.ws + n % a.ws;
+            const int col = which * a.dim + head * hd + c;
+            v = (y < a.g && x < a.g) ? qkv[((size_t)b * a.g * a.g + (size_t)y * a.g + x) * 3 * a.dim + col] : qkv_bias[col];
+        }
+        sq[which][t][c] = v;
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf(float(hd));   // head_dim ** -0.5 (image_encoder.py:206): 0.125 or 0.1118034
+    float amax = 0.f;
+    const size_t row0 = (size_t)grp * a.Npad + n0;
+    for (int idx = tid; idx < 16 * a.DQ; idx += 256) {
+        const int t = idx / a.DQ, j = idx - t * a.DQ, n = n0 + t;
+        float qv = 0.f, kv = 0.f;
+        if (n < a.Nq) {
+            const int qh = n / a.ws, qw = n - qh * a.ws;
+            if (j < hd) {
+                qv = sq[0][t][j] * scale;
+                kv = sq[1][t][j];
+            } else if (j < hd + 2 * a.ws) {
+                const int jj = j - hd;
+                const float* R = jj < a.ws ? Rh + ((size_t)qh * a.ws + jj) * hd : Rw + ((size_t)qw * a.ws + (jj - a.ws)) * hd;
+                float acc = 0.f;
+                for (int c = 0; c < hd; c += 4) {
+                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(R + c);
+                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(&sq[0][t][c]);
+                    acc = fmaf(q4[0], r4[0], acc);
+                    acc = fmaf(q4[1], r4[1], acc);
+                    acc = fmaf(q4[2], r4[2], acc);
+                    acc = fmaf(q4[3], r4[3], acc);
+                }
+                qv = acc;
+                kv = (jj < a.ws ? jj == qh : jj - a.ws == qw) ? 1.f : 0.f;
+            }
+        }
+        qv *= L2E;   // scores leave the MFMA in the log2 domain
+        amax = fmaxf(amax, fmaxf(fabsf(qv), fabsf(kv)));
+        if (!(qv == qv) || !(kv == kv)) amax = INFINITY;
+        const _Float16 qhi = _Float16(qv), khi = _Float16(kv);
+        _Float16* qo = Qp + (row0 + t) * 2 * a.DQ + j;
+        qo[0] = qhi;
+        qo[a.DQ] = _Float16(qv - float(qhi));
+        _Float16* ko = Kp + (row0 + t) * (a.DQ + a.HDP) + j;
+        ko[0] = khi;
+        if (j < a.HDP) ko[a.DQ] = _Float16(kv - float(khi));
+    }
+    for (int idx = tid; idx < 16 * a.DV; idx += 256) {
+        const int t = idx / a.DV, j = idx - t * a.DV, n = n0 + t;
+        const float v = (n < a.Nq && j < hd) ? sq[2][t][j] : 0.f;
+        amax = fmaxf(amax, fabsf(v));
+        if (!(v == v)) amax = INFINITY;
+        const _Float16 hi = _Float16(v);
+        _Float16* vo = Vp + (row0 + t) * 2 * a.DV + j;
+        vo[0] = hi;
+        vo[a.DV] = _Float16(v - float(hi));
+    }
+    pope_range_flag(range_flag, POPE_RANGE_QKV, !(amax < POPE_F16_OVERFLOW));
+}
+
+// ---- flash attention over the widened operands ----------------------------------------------------------------------
+constexpr int WAVES = 8, NT = 64 * WAVES, QB = 32 * WAVES, KT = 32;
+
+template <int NSTEP, int HSTEP, int DVT>
+struct AttnCfg {
+    static constexpr int DQ = 16 * NSTEP, HDP = 16 * HSTEP, DV = 32 * DVT;
+    static constexpr int KST = DQ + 8, KLST = HDP + 8, VST = DV + 8;   // LDS row strides (halves): odd multiples of 16 bytes
+    static constexpr int K_UNITS_ROW = (DQ + HDP) / 8, V_UNITS_ROW = 2 * DV / 8;   // 16-byte pieces per global row
+    static constexpr int K_UNITS = KT * K_UNITS_ROW, V_UNITS = KT * V_UNITS_ROW;
+    static constexpr int KP = (K_UNITS + NT - 1) / NT, VP = (V_UNITS + NT - 1) / NT;
+    static constexpr int OST = HDP + 4;                                 // epilogue staging row (floats)
+    static constexpr size_t STAGE_BYTES = size_t(KT) * (KST + KLST + 2 * VST) * sizeof(_Float16);
+    static constexpr size_t EPI_BYTES = size_t(QB) * OST * sizeof(float);
+    static constexpr size_t LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+};
+
+template <int NSTEP, int HSTEP, int DVT>
+__global__ __launch_bounds__(NT, 1) void sam_attn_kernel(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp,
+                                                         const _Float16* __restrict__ Vp, _Float16* __restrict__ out_pl,
+                                                         AttnGeom a, unsigned* range_flag) {
+    using C = AttnCfg<NSTEP, HSTEP, DVT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Kh = reinterpret_cast<_Float16*>(smem);
+    _Float16* Kl = Kh + KT * C::KST;
+    _Float16* Vh = Kl + KT * C::KLST;
+    _Float16* Vl = Vh + KT * C::VST;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_qb = (a.Nq + QB - 1) / QB;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);   // the query blocks of one (window, head) share an XCD's L2
+    const int grp = logical / n_qb, q0 = (logical - grp * n_qb) * QB;
+    const int head = grp % a.heads, wb = grp / a.heads;
+
+    // Q'^T fragments (B operand of S^T = K'.Q'^T): lane (r, h) holds Q'[q = r][16 kg + 8 h + 0..7]; rows past Npad
+    // read as zeros (buffer range check) — their waves only keep the barriers company
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(Qp + (size_t)grp * a.Npad * 2 * C::DQ), 0, unsigned(a.Npad) * 2u * C::DQ * 2u, 0x00020000);
+    f16x8 qh[NSTEP], ql[NSTEP];
+    {
+        const unsigned qoff = unsigned(q0 + wave * 32 + r) * unsigned(2 * C::DQ * 2) + unsigned(8 * h) * 2u;
+#pragma unroll
+        for (int kg = 0; kg < NSTEP; ++kg) {
+            qh[kg] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + kg * 32u, 0, 0));
+            ql[kg] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + C::DQ * 2u + kg * 32u, 0, 0));
+        }
+    }
+
+    // K' / V tiles: 32 consecutive rows of the group are one contiguous blob; 16-byte pieces go to the padded LDS rows
+    const u32x4* kg_base = reinterpret_cast<const u32x4*>(Kp + (size_t)grp * a.Npad * (C::DQ + C::HDP));
+    const u32x4* vg_base = reinterpret_cast<const u32x4*>(Vp + (size_t)grp * a.Npad * 2 * C::DV);
+    u32x4 rk[C::KP], rv[C::VP];
+    auto load_kv = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < C::KP; ++i) {
+            const int u = tid + NT * i;
+            if (C::K_UNITS % NT == 0 || u < C::K_UNITS) rk[i] = kg_base[(size_t)kt * C::K_UNITS + u];
+        }
+#pragma unroll
+        for (int i = 0; i < C::VP; ++i) {
+            const int u = tid + NT * i;
+            if (C::V_UNITS % NT == 0 || u < C::V_UNITS) rv[i] = vg_base[(size_t)kt * C::V_UNITS + u];
+        }
+    };
+    auto store_kv = [&]() {
+#pragma unroll
+        for (int i = 0; i < C::KP; ++i) {
+            const int u = tid + NT * i;
+            if (C::K_UNITS % NT == 0 || u < C::K_UNITS) {
+                const int row = u / C::K_UNITS_ROW, c = u - row * C::K_UNITS_ROW;
+                _Float16* dst = c < C::DQ / 8 ? Kh + row * C::KST + c * 8 : Kl + row * C::KLST + (c - C::DQ / 8) * 8;
+                *reinterpret_cast<u32x4*>(dst) = rk[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::VP; ++i) {
+            const int u = tid + NT * i;
+            if (C::V_UNITS % NT == 0 || u < C::V_UNITS) {
+                const int row = u / C::V_UNITS_ROW, c = u - row * C::V_UNITS_ROW;
+                _Float16* dst = c < C::DV / 8 ? Vh + row * C::VST + c * 8 : Vl + row * C::VST + (c - C::DV / 8) * 8;
+                *reinterpret_cast<u32x4*>(dst) = rv[i];
+            }
+        }
+    };
+
+    // ds_read_b64_tr_b16 addressing of the V^T fragments (A operand of O^T += V^T.P^T), as attention_f16x3.hip: the
+    // block of lane l covers keys 4 (l >> 5) + q (+ 16 s, + 8) and value columns 16 ((l >> 4) & 1) + 4 p (+ 32 dt)
+    const int tr_off = (4 * h + ((lane & 15) >> 2)) * C::VST + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto vfrag = [&](const _Float16* plane, int s, int dt) {
+        const _Float16* p = plane + tr_off + (16 * s) * C::VST + 32 * dt;
+        const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+        const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 8 * C::VST));
+        return cat(__builtin_bit_cast(f16x4, x), __builtin_bit_cast(f16x4, y));
+    };
+
+    f32x16 o[DVT];
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+    float m_run = -INFINITY;    // running max (log2 domain)
+    f32x2 l_run = {0.f, 0.f};   // running sum of the 2^10-scaled probabilities, two partial lanes
+
+    const int nkt = a.Npad / KT;
+    load_kv(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt) __syncthreads();   // every wave is done with the previous tile
+        store_kv();
+        __syncthreads();
+        if (kt + 1 < nkt) load_kv(kt + 1);
+
+        // ---- S^T = K'.Q'^T: 3 MFMAs per 16-wide step over q / k proper, 2 over the one-hot columns (no lo plane)
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+        const _Float16* kb_h = Kh + r * C::KST + 8 * h;
+        const _Float16* kb_l = Kl + r * C::KLST + 8 * h;
+#pragma unroll
+        for (int kg = 0; kg < NSTEP; ++kg) {
+            const f16x8 kh = *reinterpret_cast<const f16x8*>(kb_h + 16 * kg);
+            if (kg < HSTEP) {
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(kb_l + 16 * kg);
+                s = mfma_f16(kl, qh[kg], s);
+            }
+            s = mfma_f16(kh, ql[kg], s);
+            s = mfma_f16(kh, qh[kg], s);
+        }
+        if (kt + 1 == nkt) {   // keys past the window (rows Nq..Npad of the planes are zeros)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (kt * KT + mfma32_row(i, h) >= a.Nq) s[i] = -INFINITY;
+        }
+        // ---- online softmax in registers (log2 domain; p' = 2^(s - m + 10), the 2^10 cancels in O / l)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s));   // XDL write -> asm VALU read wait states
+        float mt = vmax3(s[0], s[1], s[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mt = vmax3(mt, s[i], s[i + 1]);
+        mt = __builtin_fmaxf(mt, s[15]);
+        mt = __builtin_fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = __builtin_fmaxf(m_run, mt);
+        if (__any(m_new > m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run = l_run * alpha;
+#pragma unroll
+            for (int dt = 0; dt < DVT; ++dt) o[dt] *= alpha;
+        }
+        m_run = m_new;
+        const float mshift = m_new - 10.0f;
+        f32x2 ls = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            s[i] = __builtin_amdgcn_exp2f(s[i] - mshift);
+            s[i + 1] = __builtin_amdgcn_exp2f(s[i + 1] - mshift);
+            ls += f32x2{s[i], s[i + 1]};
+        }
+        l_run += ls;
+
+        // ---- O^T += V^T.P^T: score registers 8 s .. 8 s + 7 are the B fragment of k-step s
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f32x4 p0, p1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                p0[e] = s[8 * st + e];
+                p1[e] = s[8 * st + 4 + e];
+            }
+            f16x4 h0, l0, h1, l1;
+            pope_split4(p0, h0, l0);
+            pope_split4(p1, h1, l1);
+            const f16x8 ph = cat(h0, h1), pl = cat(l0, l1);
+#pragma unroll
+            for (int dt = 0; dt < DVT; ++dt) {
+                const f16x8 vh = vfrag(Vh, st, dt), vl = vfrag(Vl, st, dt);
+                o[dt] = mfma_f16(vl, ph, o[dt]);
+                o[dt] = mfma_f16(vh, pl, o[dt]);
+                o[dt] = mfma_f16(vh, ph, o[dt]);
+            }
+        }
+    }
+    __syncthreads();   // the stage is free: reuse it for the O^T transposition
+
+    // normalise, transpose through LDS, un-partition (image_encoder.py:262-285: pad queries are dropped) and write the
+    // activation planes of the proj GEMM: [B g g, dim], column head * hd + d
+    const float l_half = l_run[0] + l_run[1];
+    const float inv = 1.0f / (l_half + __shfl_xor(l_half, 32));
+    float* Os = smem + (wave * 32) * C::OST;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            if (32 * dt + 8 * g4 + 4 * h < C::HDP) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[dt][4 * g4 + e] * inv;
+                *reinterpret_cast<f32x4*>(&Os[r * C::OST + 32 * dt + 8 * g4 + 4 * h]) = v;
+            }
+        }
+    __builtin_amdgcn_wave_barrier();
+    const int win = wb % (a.nw * a.nw), b = wb / (a.nw * a.nw);
+    const int wy = win / a.nw, wx = win - wy * a.nw;
+    constexpr int QUADS = C::HDP / 4;   // 16-byte pieces per head row
+    f32x2 amax = {0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < 32 * QUADS / 64; ++it) {
+        const int item = it * 64 + lane, lr = item / QUADS, c4 = (item - lr * QUADS) * 4;
+        const int n = q0 + wave * 32 + lr;
+        const int y = wy * a.ws + n / a.ws, x = wx * a.ws + n % a.ws;
+        if (n < a.Nq && y < a.g && x < a.g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&Os[lr * C::OST + c4]);
+            pope_amax4x2(amax, v);
+            f16x4 hi, lo;
+            pope_split4(v * A_SCALE, hi, lo);
+            const int col = head * C::HDP + c4;
+            _Float16* dst = out_pl + ((size_t)b * a.g * a.g + (size_t)y * a.g + x) * 2 * a.dim + (col >> 5) * 64 + (col & 31);
+            *reinterpret_cast<f16x4*>(dst) = hi;
+            *reinterpret_cast<f16x4*>(dst + 32) = lo;
+        }
+    }
+    pope_range_flag(range_flag, POPE_RANGE_QKV, !(fmaxf(amax[0], amax[1]) * A_SCALE < POPE_F16_OVERFLOW));
+}
+
+// ---- neck LayerNorm2d (common.py:27-43: per pixel over the channels, eps inside the sqrt, a true division) -----------
+// in: fp32 [pixels, C] (C % 256 == 0, <= 1024); one wave per pixel, four channels per lane and 256-column group
+template <bool TO_BORDERED_PLANES>
+__global__ __launch_bounds__(256) void sam_ln2d_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ bvec, void* __restrict__ out, int B, int g, int C,
+                                                       float eps, unsigned* range_flag) {
+    // TO_BORDERED_PLANES: in = [B g g, C] rows, out = activation planes [B, g + 2, g + 2, C] with a zero border (the
+    //   3x3 convolution's operand, conv.hip layout); the wave index walks the BORDERED pixels
+    // else: in = fp32 [B, g + 2, g + 2, C] (the convolution's bordered output), out = fp32 NCHW [B, C, g, g]; the wave
+    //   index walks the interior pixels
+    const int gp = g + 2, nv = C / 256;
+    const int lane = threadIdx.x & 63;
+    const long long waves = (long long)gridDim.x * 4, total = (long long)B * (TO_BORDERED_PLANES ? gp * gp : g * g);
+    float amax = 0.f;
+    for (long long pix = blockIdx.x * 4ll + (threadIdx.x >> 6); pix < total; pix += waves) {
+        int b, y, x;   // interior coordinates
+        if (TO_BORDERED_PLANES) {
+            b = int(pix / (gp * gp));
+            const int rem = int(pix - (long long)b * gp * gp);
+            y = rem / gp - 1;
+            x = rem % gp - 1;
+        } else {
+            b = int(pix / (g * g));
+            const int rem = int(pix - (long long)b * g * g);
+            y = rem / g;
+            x = rem % g;
+        }
+        const bool interior = y >= 0 && y < g && x >= 0 && x < g;
+        f32x4 v[4] = {};
+        float sum = 0.f;
+        const float* src = TO_BORDERED_PLANES ? in + ((size_t)b * g * g + (size_t)y * g + x) * C
+                                              : in + ((size_t)b * gp * gp + (size_t)(y + 1) * gp + (x + 1)) * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (interior && k < nv) {
+                v[k] = *reinterpret_cast<const f32x4*>(src + k * 256 + lane * 4);
+                sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+            }
+        const float u = wave_sum(sum) / float(C);
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (interior && k < nv) {
+                v[k] = v[k] - u;
+                sq += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+            }
+        const float den = sqrtf(wave_sum(sq) / float(C) + eps);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= nv) continue;
+            const int col = k * 256 + lane * 4;
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (interior) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(w + col), b4 = *reinterpret_cast<const f32x4*>(bvec + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = w4[e] * (v[k][e] / den) + b4[e];
+            }
+            if (TO_BORDERED_PLANES) {
+                amax = pope_amax4(amax, r);
+                if (!((r[0] + r[1]) + (r[2] + r[3]) == (r[0] + r[1]) + (r[2] + r[3]))) amax = INFINITY;
+                f16x4 hi, lo;
+                pope_split4(r * A_SCALE, hi, lo);
+                _Float16* dst = static_cast<_Float16*>(out) + (size_t)pix * 2 * C + (col >> 5) * 64 + (col & 31);
+                *reinterpret_cast<f16x4*>(dst) = hi;
+                *reinterpret_cast<f16x4*>(dst + 32) = lo;
+            } else {
+                float* dst = static_cast<float*>(out) + (((size_t)b * C + col) * g + y) * g + x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[(size_t)e * g * g] = r[e];
+            }
+        }
+    }
+    if (TO_BORDERED_PLANES) pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax * A_SCALE < POPE_F16_OVERFLOW));
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------
+struct AttnPlan {
+    AttnGeom geom;
+    int nstep;      // DQ / 16
+    size_t qp, kp, vp;   // bytes
+};
+
+// the smallest instantiated score depth that holds hd + 2 ws columns
+bool plan_attention(int B, int g, int ws, int heads, int hd, AttnPlan& p) {
+    AttnGeom& a = p.geom;
+    a.B = B; a.g = g; a.ws = ws; a.nw = (g + ws - 1) / ws;
+    a.heads = heads; a.hd = hd; a.dim = heads * hd;
+    a.Nq = ws * ws; a.Npad = (a.Nq + KT - 1) / KT * KT;
+    a.HDP = hd; a.DV = hd == 80 ? 96 : 64;
+    const int need = hd + 2 * ws;
+    static const int depths80[] = {7, 13}, depths64[] = {6, 12};
+    const int* d = hd == 80 ? depths80 : depths64;
+    p.nstep = 16 * d[0] >= need ? d[0] : (16 * d[1] >= need ? d[1] : 0);
+    if (!p.nstep) return false;
+    a.DQ = 16 * p.nstep;
+    const size_t G = size_t(B) * a.nw * a.nw * heads;
+    p.qp = G * a.Npad * 2 * a.DQ * sizeof(_Float16);
+    p.kp = G * a.Npad * (a.DQ + a.HDP) * sizeof(_Float16);
+    p.vp = G * a.Npad * 2 * a.DV * sizeof(_Float16);
+    return true;
+}
+
+template <int NSTEP, int HSTEP, int DVT>
+int launch_attn(const AttnPlan& p, const _Float16* Qp, const _Float16* Kp, const _Float16* Vp, _Float16* out, unsigned* flag,
+                hipStream_t stream) {
+    using C = AttnCfg<NSTEP, HSTEP, DVT>;
+    static pope_dev_mask done{0};
+    auto kern = sam_attn_kernel<NSTEP, HSTEP, DVT>;
+    if (!pope_opt_in_lds(kern, C::LDS_BYTES, done)) return POPE_ERR_LAUNCH;
+    const AttnGeom& a = p.geom;
+    const long long blocks = (long long)a.B * a.nw * a.nw * a.heads * ((a.Nq + QB - 1) / QB);
+    if (blocks <= 0 || blocks > 0x7fffffffll) return POPE_ERR_ARG;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), C::LDS_BYTES, stream, Qp, Kp, Vp, out, a, flag);
+    return pope_check_launch();
+}
+
+}  // namespace
+
+size_t pope_sam_encoder_workspace(const SamEncParams& q) {
+    if (q.B <= 0 || q.img <= 0 || q.patch <= 0 || q.img % q.patch || q.heads <= 0 || q.dim % q.heads) return 0;
+    const int g = q.img / q.patch, hd = q.dim / q.heads;
+    const size_t rows = size_t(q.B) * g * g;
+    const size_t kp = size_t(3) * q.patch * q.patch;
+    size_t big = rows * 4 * q.dim * 4;                      // qkv fp32 [rows, 3 dim] + attention output planes [rows, dim]
+    if (rows * q.hidden * 4 > big) big = rows * q.hidden * 4;   // fc1 output planes
+    if (rows * kp * 4 > big) big = rows * kp * 4;               // im2col planes
+    size_t ops = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        AttnPlan p;
+        const int ws = pass ? g : (q.window > 0 ? q.window : g);
+        if (!plan_attention(q.B, g, ws, q.heads, hd, p)) return 0;
+        const size_t need = align256(p.qp) + align256(p.kp) + align256(p.vp);
+        if (need > ops) ops = need;
+    }
+    const size_t gp = size_t(g) + 2;
+    return align256(rows * q.dim * 4) /* x */ + align256(rows * q.dim * 4) /* xn planes */ + align256(big) + ops +
+           align256(rows * q.out_chans * 4) /* neck 1x1 */ + 2 * align256(size_t(q.B) * gp * gp * q.out_chans * 4);
+}
+
+int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
+    if (!q.image || !q.out || !q.ws || !q.blocks || !q.patch_wp || !q.patch_b || !q.ones || !q.neck0_wp || !q.neck2_wp ||
+        !q.neck1_w || !q.neck1_b || !q.neck3_w || !q.neck3_b)
+        return POPE_ERR_ARG;
+    if (q.B <= 0 || q.depth <= 0 || q.patch <= 0 || (q.patch & 7) || q.img % q.patch || q.heads <= 0 || q.dim % q.heads)
+        return POPE_ERR_ARG;
+    const int g = q.img / q.patch, hd = q.dim / q.heads, dim = q.dim, hidden = q.hidden, oc = q.out_chans;
+    if ((hd != 64 && hd != 80) || (dim & 127) || dim > 2048 || (hidden & 31) || (oc & 255) || oc > 1024 || q.window < 0) return POPE_ERR_ARG;
+    const int kp = 3 * q.patch * q.patch;
+    if (kp & 31) return POPE_ERR_ARG;
+    const size_t need = pope_sam_encoder_workspace(q);
+    if (!need) return POPE_ERR_ARG;
+    if (q.ws_bytes < need) return POPE_ERR_WORKSPACE;
+    const int rows = q.B * g * g;
+    const size_t gp = size_t(g) + 2, brows = size_t(q.B) * gp * gp;
+    if (size_t(rows + 256) * (hidden > 3 * dim ? hidden : 3 * dim) * 4 >= (1ull << 32) - 512 || brows * oc * 4 >= (1ull << 32) - 512)
+        return POPE_ERR_ARG;   // 32-bit buffer offsets in the GEMMs: the caller splits larger batches
+
+    AttnPlan plan_w, plan_g;
+    if (!plan_attention(q.B, g, q.window > 0 ? q.window : g, q.heads, hd, plan_w) || !plan_attention(q.B, g, g, q.heads, hd, plan_g))
+        return POPE_ERR_ARG;
+
+    char* base = static_cast<char*>(q.ws);
+    auto take = [&](size_t bytes) { char* p = base; base += align256(bytes); return p; };
+    float* x = reinterpret_cast<float*>(take(size_t(rows) * dim * 4));
+    void* xn_pl = take(size_t(rows) * dim * 4);
+    size_t big_bytes = size_t(rows) * 4 * dim * 4;
+    if (size_t(rows) * hidden * 4 > big_bytes) big_bytes = size_t(rows) * hidden * 4;
+    if (size_t(rows) * kp * 4 > big_bytes) big_bytes = size_t(rows) * kp * 4;
+    char* big = take(big_bytes);
+    float* qkv = reinterpret_cast<float*>(big);
+    void* att_pl = big + size_t(rows) * 3 * dim * 4;
+    void* hid_pl = big;
+    size_t ops = 0;
+    for (const AttnPlan* p : {&plan_w, &plan_g}) {
+        const size_t n = align256(p->qp) + align256(p->kp) + align256(p->vp);
+        if (n > ops) ops = n;
+    }
+    char* op_base = take(ops);
+    float* t1 = reinterpret_cast<float*>(take(size_t(rows) * oc * 4));
+    void* t1_pl = take(brows * oc * 4);
+    float* t2 = reinterpret_cast<float*>(take(brows * oc * 4));
+
+    const float eps = 1e-6f;   // build_sam.py:71; common.py:32
+    unsigned* flag = q.range_flag;
+    int rc;
+#define POPE_TRY(call) do { if ((rc = (call))) return rc; } while (0)
+    auto gemm = [&](const void* a_pl, const void* w_pl, const float* bias, float* Cf, void* c_pl, int N, int K, int epi,
+                    const float* gamma, const float* res, int res_mod) {
+        GemmParams gp_ = {};
+        gp_.range_flag = flag;
+        gp_.range_bit = epi == EPI_BIAS_GELU ? POPE_RANGE_GELU : POPE_RANGE_QKV;
+        gp_.a_pl = a_pl; gp_.w_pl = w_pl; gp_.bias = bias; gp_.C = Cf; gp_.c_pl = c_pl;
+        gp_.lda = K; gp_.ldw = K; gp_.ldc = N; gp_.M = rows; gp_.N = N; gp_.K = K;
+        gp_.epilogue = epi; gp_.gamma = gamma; gp_.res = res; gp_.ldres = N; gp_.res_mod = res_mod;
+        return pope_launch_gemm_nt_f16x3_planes(gp_, stream);
+    };
+
+    // patch embed + absolute position table (image_encoder.py:108-110): x = conv(img) + bias + pos[token]
+    {
+        const long long total = (long long)rows * (kp / 8);
+        hipLaunchKernelGGL(sam_im2col_kernel, dim3(grid_for(total)), dim3(256), 0, stream, q.image, reinterpret_cast<_Float16*>(big),
+                           q.B, q.img, q.patch, flag);
+        POPE_TRY(pope_check_launch());
+        if (q.pos) POPE_TRY(gemm(big, q.patch_wp, q.patch_b, x, nullptr, dim, kp, EPI_BIAS_LS_RES, q.ones, q.pos, g * g));
+        else POPE_TRY(gemm(big, q.patch_wp, q.patch_b, x, nullptr, dim, kp, EPI_BIAS, nullptr, nullptr, 0));
+    }
+    for (int i = 0; i < q.depth; ++i) {
+        const SamBlockParams& k = q.blocks[i];
+        if (!k.norm1_w || !k.norm1_b || !k.qkv_wp || !k.qkv_b || !k.proj_wp || !k.proj_b || !k.norm2_w || !k.norm2_b || !k.fc1_wp ||
+            !k.fc1_b || !k.fc2_wp || !k.fc2_b || !k.rel_h || !k.rel_w)
+            return POPE_ERR_ARG;
+        const AttnPlan& p = k.global || q.window <= 0 ? plan_g : plan_w;
+        const AttnGeom& a = p.geom;
+        // x = x + attn(norm1(x))                                         image_encoder.py:166-179
+        POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm1_w, k.norm1_b, xn_pl, rows, dim, eps, flag, stream));
+        POPE_TRY(gemm(xn_pl, k.qkv_wp, k.qkv_b, qkv, nullptr, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, 0));
+        _Float16* Qp = reinterpret_cast<_Float16*>(op_base);
+        _Float16* Kp = reinterpret_cast<_Float16*>(op_base + align256(p.qp));
+        _Float16* Vp = reinterpret_cast<_Float16*>(op_base + align256(p.qp) + align256(p.kp));
+        const int G = a.B * a.nw * a.nw * a.heads;
+        hipLaunchKernelGGL(sam_attn_prep_kernel, dim3(a.Npad / 16, G), dim3(256), 0, stream, qkv, k.qkv_b, k.rel_h, k.rel_w, Qp, Kp,
+                           Vp, a, flag);
+        POPE_TRY(pope_check_launch());
+        _Float16* att = static_cast<_Float16*>(att_pl);
+        if (hd == 80) {
+            if (p.nstep == 7) POPE_TRY((launch_attn<7, 5, 3>(p, Qp, Kp, Vp, att, flag, stream)));
+            else POPE_TRY((launch_attn<13, 5, 3>(p, Qp, Kp, Vp, att, flag, stream)));
+        } else {
+            if (p.nstep == 6) POPE_TRY((launch_attn<6, 4, 2>(p, Qp, Kp, Vp, att, flag, stream)));
+            else POPE_TRY((launch_attn<12, 4, 2>(p, Qp, Kp, Vp, att, flag, stream)));
+        }
+        POPE_TRY(gemm(att_pl, k.proj_wp, k.proj_b, x, nullptr, dim, dim, EPI_BIAS_LS_RES, q.ones, x, 0));
+        // x = x + mlp(norm2(x))                                          image_encoder.py:181; common.py:13-25
+        POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm2_w, k.norm2_b, xn_pl, rows, dim, eps, flag, stream));
+        POPE_TRY(gemm(xn_pl, k.fc1_wp, k.fc1_b, nullptr, hid_pl, hidden, dim, EPI_BIAS_GELU, nullptr, nullptr, 0));
+        POPE_TRY(gemm(hid_pl, k.fc2_wp, k.fc2_b, x, nullptr, dim, hidden, EPI_BIAS_LS_RES, q.ones, x, 0));
+        for (int t = 0; t < q.n_taps; ++t)
+            if (q.tap_blocks[t] == i && q.tap_out[t] &&
+                hipMemcpyAsync(q.tap_out[t], x, size_t(rows) * dim * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                return POPE_ERR_LAUNCH;
+    }
+    // neck (image_encoder.py:89-105): 1x1 conv (no bias) -> LayerNorm2d -> 3x3 conv pad 1 (no bias) -> LayerNorm2d
+    POPE_TRY(pope_launch_split_planes(x, xn_pl, rows, dim, A_SCALE, flag, stream));
+    POPE_TRY(gemm(xn_pl, q.neck0_wp, nullptr, t1, nullptr, oc, dim, EPI_BIAS, nullptr, nullptr, 0));
+    hipLaunchKernelGGL(sam_ln2d_kernel<true>, dim3(grid_for((long long)brows, 4)), dim3(256), 0, stream, t1, q.neck1_w, q.neck1_b, t1_pl,
+                       q.B, g, oc, eps, flag);
+    POPE_TRY(pope_check_launch());
+    {
+        GemmParams c = {};
+        const int Wp = g + 2;
+        const size_t shift = size_t(Wp) + 1;   // output row R is pixel R + Wp + 1 (conv.hip)
+        c.a_pl = t1_pl; c.w_pl = q.neck2_wp; c.bias = nullptr;
+        c.lda = oc; c.ldw = 9 * oc; c.ldc = oc;
+        c.M = int(brows - (2 * size_t(Wp) + 2)); c.N = oc; c.K = 9 * oc;
+        c.epilogue = EPI_CONV; c.act_slope = 1.0f;   // identity
+        c.C = t2 + shift * oc;
+        c.conv_cch = oc / 32; c.conv_wp = Wp;
+        c.range_flag = flag; c.range_bit = POPE_RANGE_INPUT;
+        c.nbatch = 1;
+        POPE_TRY(pope_launch_planes16(c, stream));
+    }
+    hipLaunchKernelGGL(sam_ln2d_kernel<false>, dim3(grid_for((long long)rows, 4)), dim3(256), 0, stream, t2, q.neck3_w, q.neck3_b, q.out,
+                       q.B, g, oc, eps, nullptr);
+    POPE_TRY(pope_check_launch());
+#undef POPE_TRY
+    return POPE_OK;
+}

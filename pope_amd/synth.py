@@ -53,6 +53,47 @@ def synthetic_state_dict(seed=0, dim=384, depth=12, patch=14, grid=37, gamma=1.0
     return sd
 
 
+def synthetic_sam_encoder_state_dict(seed=0, dim=1280, depth=32, heads=16, grid=64, window=14, global_idx=(7, 15, 23, 31),
+                                     patch=16, out_chans=256):
+    """Seeded synthetic weights in the layout of SAM's `ImageEncoderViT` state dict
+    (segment_anything/segment_anything/modeling/image_encoder.py:53-105, build_sam.py:66-79; ViT-H defaults).  Branch
+    outputs and the relative-position terms are O(1) so windows, padding keys and the bias all matter."""
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, std=1.0):
+        return torch.randn(*shape, generator=g, dtype=torch.float32) * std
+
+    hd = dim // heads
+    sd = {"pos_embed": rn(1, grid, grid, dim, std=0.2)}
+    k_pe = 3 * patch * patch
+    sd["patch_embed.proj.weight"] = rn(dim, 3, patch, patch, std=1.0 / math.sqrt(k_pe))
+    sd["patch_embed.proj.bias"] = rn(dim, std=0.1)
+    for i in range(depth):
+        p = f"blocks.{i}."
+        size = grid if i in global_idx else window
+        sd[p + "norm1.weight"] = 1.0 + rn(dim, std=0.1)
+        sd[p + "norm1.bias"] = rn(dim, std=0.05)
+        sd[p + "attn.qkv.weight"] = rn(3 * dim, dim, std=1.5 / math.sqrt(dim))
+        sd[p + "attn.qkv.bias"] = rn(3 * dim, std=0.1)
+        sd[p + "attn.proj.weight"] = rn(dim, dim, std=0.3 / math.sqrt(dim))
+        sd[p + "attn.proj.bias"] = rn(dim, std=0.02)
+        sd[p + "attn.rel_pos_h"] = rn(2 * size - 1, hd, std=0.15)
+        sd[p + "attn.rel_pos_w"] = rn(2 * size - 1, hd, std=0.15)
+        sd[p + "norm2.weight"] = 1.0 + rn(dim, std=0.1)
+        sd[p + "norm2.bias"] = rn(dim, std=0.05)
+        sd[p + "mlp.lin1.weight"] = rn(4 * dim, dim, std=1.0 / math.sqrt(dim))
+        sd[p + "mlp.lin1.bias"] = rn(4 * dim, std=0.1)
+        sd[p + "mlp.lin2.weight"] = rn(dim, 4 * dim, std=0.3 / math.sqrt(4 * dim))
+        sd[p + "mlp.lin2.bias"] = rn(dim, std=0.02)
+    sd["neck.0.weight"] = rn(out_chans, dim, 1, 1, std=1.0 / math.sqrt(dim))
+    sd["neck.1.weight"] = 1.0 + rn(out_chans, std=0.1)
+    sd["neck.1.bias"] = rn(out_chans, std=0.05)
+    sd["neck.2.weight"] = rn(out_chans, out_chans, 3, 3, std=1.0 / math.sqrt(9 * out_chans))
+    sd["neck.3.weight"] = 1.0 + rn(out_chans, std=0.1)
+    sd["neck.3.bias"] = rn(out_chans, std=0.05)
+    return sd
+
+
 def synthetic_images(batch, h=476, w=630, seed=0, device="cpu"):
     """Uniform[0,1) 640x480 frames, centre-cropped to (h, w) and normalised with
     the ImageNet statistics of set_torch_image."""
