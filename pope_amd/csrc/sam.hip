@@ -8,8 +8,8 @@
 //     K'[m] = [ k[m]       | onehot(kh(m))          | onehot(kw(m))          ]
 // so Q'.K'^T is the biased score and the flash kernel needs no bias path at all: the relative-position terms ride on
 // the matrix cores (K' one-hot columns are exact in f16 and have no lo plane: 2 MFMAs per step there instead of 3).
-// `sam_attn_prep_kernel` builds Q', K', V as f16 hi/lo planes per (window, head) straight from the QKV GEMM's fp32
-// output — it also does the window partition, and the zero-padded tokens of the bottom / right windows
+// `sam_attn_split_kernel` + `sam_attn_relpos_kernel` build Q', K', V as f16 hi/lo planes per (window, head) straight from
+// the QKV GEMM's fp32 output — they also do the window partition, and the zero-padded tokens of the bottom / right windows
 // (image_encoder.py:251-254, padded AFTER norm1) get k = v = the qkv bias, exactly what Linear(0) gives the reference.
 // `sam_attn_kernel` is the single-stage f16x3 flash kernel of attention_f16x3.hip re-cut for 32-key tiles, a
 // K depth of 16 * NSTEP and 32 * DVT value columns; its epilogue un-partitions (drops the pad queries) and writes the
@@ -81,79 +81,126 @@ struct AttnGeom {
     int DQ, HDP, DV;      // score depth (16 * NSTEP >= hd + 2 ws), lo-plane depth (= hd), value columns (32 * DVT)
 };
 
-// Q' / K' / V planes of one block's attention, 16 tokens of one (window, head) per workgroup.
-//   Qp [G][Npad][DQ hi | DQ lo], Kp [G][Npad][DQ hi | hd lo], Vp [G][Npad][DV hi | DV lo]   (halves; G = B nw^2 heads)
-// Rh / Rw: [ws][ws][hd] fp32, the gathered tables get_rel_pos returns (image_encoder.py:288-316; host, once per model).
-__global__ __launch_bounds__(256) void sam_attn_prep_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
-                                                            const float* __restrict__ Rh, const float* __restrict__ Rw,
-                                                            _Float16* __restrict__ Qp, _Float16* __restrict__ Kp,
-                                                            _Float16* __restrict__ Vp, AttnGeom a, unsigned* range_flag) {
-    __shared__ __attribute__((aligned(16))) float sq[3][16][80];
-    const int tid = threadIdx.x;
-    const int grp = blockIdx.y, n0 = blockIdx.x * 16;
-    const int head = grp % a.heads, wb = grp / a.heads;
+// Operand planes of one block's attention (halves; G = B nw^2 heads groups, n = token inside its window):
+//   Qp [G][Npad][DQ hi | DQ lo], Kp [G][Npad][DQ hi | hd lo], Vp [G][Npad][DV hi | DV lo]
+// Rows Nq..Npad are written as zeros every time (the buffers are shared by the window and the global geometry).
+// Two kernels.  `sam_attn_split_kernel` streams: per (group, row) it converts q * scale, k and v (8 columns per thread,
+// 32-byte reads, 16-byte stores) and writes K's one-hot columns.  `sam_attn_relpos_kernel` computes the relative
+// position columns of Q': R[q][k][:] depends on the token, not on the head, so a thread owns one (token, k) pair,
+// keeps that row of Rh / Rw (hd floats) in registers and walks the heads with q broadcast from LDS — every table row
+// is read once per token instead of once per (token, head).
+__device__ __forceinline__ const float* sam_src(const float* qkv, const float* qkv_bias, const AttnGeom& a, int wb, int n, int which,
+                                                int head) {
     const int win = wb % (a.nw * a.nw), b = wb / (a.nw * a.nw);
     const int wy = win / a.nw, wx = win - wy * a.nw;
-    const int hd = a.hd;
-    for (int idx = tid; idx < 16 * 3 * hd; idx += 256) {
-        const int t = idx / (3 * hd), rem = idx - t * 3 * hd, which = rem / hd, c = rem - which * hd;
-        const int n = n0 + t;
-        float v = 0.f;
-        if (n < a.Nq) {
-            const int y = wy * a.ws + n / a.ws, x = wx * a.ws + n % a.ws;
-            const int col = which * a.dim + head * hd + c;
-            v = (y < a.g && x < a.g) ? qkv[((size_t)b * a.g * a.g + (size_t)y * a.g + x) * 3 * a.dim + col] : qkv_bias[col];
+    const int y = wy * a.ws + n / a.ws, x = wx * a.ws + n % a.ws;
+    const int col = which * a.dim + head * a.hd;
+    // tokens padded in by window_partition are zeros AFTER norm1 (image_encoder.py:173-174): Linear(0) = bias
+    return (y < a.g && x < a.g) ? qkv + ((size_t)b * a.g * a.g + (size_t)y * a.g + x) * 3 * a.dim + col : qkv_bias + col;
+}
+
+__global__ __launch_bounds__(256) void sam_attn_split_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                             _Float16* __restrict__ Qp, _Float16* __restrict__ Kp,
+                                                             _Float16* __restrict__ Vp, AttnGeom a, unsigned* range_flag) {
+    const int hp = a.hd / 8, jp = (a.DQ - a.hd) / 8, vp = a.DV / 8;
+    const int per_row = 2 * hp + jp + vp;   // q pieces | k pieces | one-hot pieces | v pieces
+    const int G = a.B * a.nw * a.nw * a.heads;
+    const long long total = (long long)G * a.Npad * per_row;
+    const float scale = 1.0f / sqrtf(float(a.hd)) * L2E;   // head_dim ** -0.5 (image_encoder.py:206), log2 domain
+    float amax = 0.f;
+    for (long long id = blockIdx.x * 256ll + threadIdx.x; id < total; id += 256ll * gridDim.x) {
+        const int piece = int(id % per_row);
+        const long long row = id / per_row;   // grp * Npad + n
+        const int n = int(row % a.Npad), grp = int(row / a.Npad);
+        const int head = grp % a.heads, wb = grp / a.heads;
+        const bool live = n < a.Nq;
+        if (piece >= 2 * hp && piece < 2 * hp + jp) {   // K' one-hot columns hd + 8 p ..: kh(n) = n / ws, kw(n) = n % ws
+            const int c0 = 8 * (piece - 2 * hp);
+            const int kh = n / a.ws, kw = n - kh * a.ws;
+            f16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (live && (c0 + e == kh || c0 + e == a.ws + kw)) ? _Float16(1.0f) : _Float16(0.0f);
+            *reinterpret_cast<f16x8*>(Kp + (size_t)row * (a.DQ + a.HDP) + a.hd + c0) = v;
+            continue;
         }
-        sq[which][t][c] = v;
+        const int which = piece < hp ? 0 : (piece < 2 * hp ? 1 : 2);
+        const int c0 = 8 * (which == 0 ? piece : (which == 1 ? piece - hp : piece - 2 * hp - jp));
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        if (live && c0 < a.hd) {
+            const float* src = sam_src(qkv, qkv_bias, a, wb, n, which, head) + c0;
+            v0 = *reinterpret_cast<const f32x4*>(src);
+            v1 = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+        if (which == 0) { v0 = v0 * scale; v1 = v1 * scale; }
+        amax = pope_amax4(pope_amax4(amax, v0), v1);
+        const float s8 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+        if (!(s8 == s8)) amax = INFINITY;
+        f16x4 h0, l0, h1, l1;
+        pope_split4(v0, h0, l0);
+        pope_split4(v1, h1, l1);
+        _Float16* hi_dst;
+        _Float16* lo_dst;
+        if (which == 0) { hi_dst = Qp + (size_t)row * 2 * a.DQ + c0; lo_dst = hi_dst + a.DQ; }
+        else if (which == 1) { hi_dst = Kp + (size_t)row * (a.DQ + a.HDP) + c0; lo_dst = hi_dst + a.DQ; }
+        else { hi_dst = Vp + (size_t)row * 2 * a.DV + c0; lo_dst = hi_dst + a.DV; }
+        *reinterpret_cast<f16x8*>(hi_dst) = cat(h0, h1);
+        *reinterpret_cast<f16x8*>(lo_dst) = cat(l0, l1);
+    }
+    pope_range_flag(range_flag, POPE_RANGE_QKV, !(amax < POPE_F16_OVERFLOW));
+}
+
+// Rh / Rw: [ws][ws][hd] fp32, the gathered tables get_rel_pos returns (image_encoder.py:288-316; host, once per model).
+// Workgroup = TPB = 256 / JT tokens of one window batch (JT = DQ - hd = 32 or 128 columns: 2 ws live ones, zeros behind).
+template <int HD>
+__global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                              const float* __restrict__ Rh, const float* __restrict__ Rw,
+                                                              _Float16* __restrict__ Qp, AttnGeom a, unsigned* range_flag) {
+    extern __shared__ __attribute__((aligned(16))) float sq[];   // [TPB][heads * HD]
+    const int JT = a.DQ - HD, TPB = 256 / JT;
+    const int tid = threadIdx.x, t = tid / JT, j = tid - t * JT;
+    const int wb = blockIdx.y, n0 = blockIdx.x * TPB;
+    for (int idx = tid; idx < TPB * a.heads * (HD / 4); idx += 256) {
+        const int tt = idx / (a.heads * (HD / 4)), rem = idx - tt * a.heads * (HD / 4);
+        const int head = rem / (HD / 4), c = (rem - head * (HD / 4)) * 4;
+        const int n = n0 + tt;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < a.Nq) v = *reinterpret_cast<const f32x4*>(sam_src(qkv, qkv_bias, a, wb, n, 0, head) + c);
+        *reinterpret_cast<f32x4*>(&sq[(tt * a.heads + head) * HD + c]) = v;
     }
     __syncthreads();
-    const float scale = 1.0f / sqrtf(float(hd));   // head_dim ** -0.5 (image_encoder.py:206): 0.125 or 0.1118034
-    float amax = 0.f;
-    const size_t row0 = (size_t)grp * a.Npad + n0;
-    for (int idx = tid; idx < 16 * a.DQ; idx += 256) {
-        const int t = idx / a.DQ, j = idx - t * a.DQ, n = n0 + t;
-        float qv = 0.f, kv = 0.f;
-        if (n < a.Nq) {
-            const int qh = n / a.ws, qw = n - qh * a.ws;
-            if (j < hd) {
-                qv = sq[0][t][j] * scale;
-                kv = sq[1][t][j];
-            } else if (j < hd + 2 * a.ws) {
-                const int jj = j - hd;
-                const float* R = jj < a.ws ? Rh + ((size_t)qh * a.ws + jj) * hd : Rw + ((size_t)qw * a.ws + (jj - a.ws)) * hd;
-                float acc = 0.f;
-                for (int c = 0; c < hd; c += 4) {
-                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(R + c);
-                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(&sq[0][t][c]);
-                    acc = fmaf(q4[0], r4[0], acc);
-                    acc = fmaf(q4[1], r4[1], acc);
-                    acc = fmaf(q4[2], r4[2], acc);
-                    acc = fmaf(q4[3], r4[3], acc);
-                }
-                qv = acc;
-                kv = (jj < a.ws ? jj == qh : jj - a.ws == qw) ? 1.f : 0.f;
-            }
-        }
-        qv *= L2E;   // scores leave the MFMA in the log2 domain
-        amax = fmaxf(amax, fmaxf(fabsf(qv), fabsf(kv)));
-        if (!(qv == qv) || !(kv == kv)) amax = INFINITY;
-        const _Float16 qhi = _Float16(qv), khi = _Float16(kv);
-        _Float16* qo = Qp + (row0 + t) * 2 * a.DQ + j;
-        qo[0] = qhi;
-        qo[a.DQ] = _Float16(qv - float(qhi));
-        _Float16* ko = Kp + (row0 + t) * (a.DQ + a.HDP) + j;
-        ko[0] = khi;
-        if (j < a.HDP) ko[a.DQ] = _Float16(kv - float(khi));
+    const int n = n0 + t;
+    const bool live = n < a.Nq && j < 2 * a.ws;
+    f32x4 R[HD / 4];
+    if (live) {
+        const int qh = n / a.ws, qw = n - qh * a.ws;
+        const float* rp = j < a.ws ? Rh + ((size_t)qh * a.ws + j) * HD : Rw + ((size_t)qw * a.ws + (j - a.ws)) * HD;
+#pragma unroll
+        for (int c = 0; c < HD / 4; ++c) R[c] = *reinterpret_cast<const f32x4*>(rp + 4 * c);
+    } else {
+#pragma unroll
+        for (int c = 0; c < HD / 4; ++c) R[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int idx = tid; idx < 16 * a.DV; idx += 256) {
-        const int t = idx / a.DV, j = idx - t * a.DV, n = n0 + t;
-        const float v = (n < a.Nq && j < hd) ? sq[2][t][j] : 0.f;
-        amax = fmaxf(amax, fabsf(v));
-        if (!(v == v)) amax = INFINITY;
-        const _Float16 hi = _Float16(v);
-        _Float16* vo = Vp + (row0 + t) * 2 * a.DV + j;
-        vo[0] = hi;
-        vo[a.DV] = _Float16(v - float(hi));
+    float amax = 0.f;
+    if (n < a.Npad) {
+        for (int head = 0; head < a.heads; ++head) {
+            const float* q = &sq[(t * a.heads + head) * HD];
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD / 4; ++c) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(q + 4 * c);
+                acc = fmaf(q4[0], R[c][0], acc);
+                acc = fmaf(q4[1], R[c][1], acc);
+                acc = fmaf(q4[2], R[c][2], acc);
+                acc = fmaf(q4[3], R[c][3], acc);
+            }
+            acc *= L2E;
+            amax = fmaxf(amax, fabsf(acc));
+            if (!(acc == acc)) amax = INFINITY;
+            const _Float16 hi = _Float16(acc);
+            _Float16* dst = Qp + ((size_t)(wb * a.heads + head) * a.Npad + n) * 2 * a.DQ + HD + j;
+            dst[0] = hi;
+            dst[a.DQ] = _Float16(acc - float(hi));
+        }
     }
     pope_range_flag(range_flag, POPE_RANGE_QKV, !(amax < POPE_F16_OVERFLOW));
 }
@@ -599,9 +646,19 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
         _Float16* Kp = reinterpret_cast<_Float16*>(op_base + align256(p.qp));
         _Float16* Vp = reinterpret_cast<_Float16*>(op_base + align256(p.qp) + align256(p.kp));
         const int G = a.B * a.nw * a.nw * a.heads;
-        hipLaunchKernelGGL(sam_attn_prep_kernel, dim3(a.Npad / 16, G), dim3(256), 0, stream, qkv, k.qkv_b, k.rel_h, k.rel_w, Qp, Kp,
-                           Vp, a, flag);
-        POPE_TRY(pope_check_launch());
+        {
+            const long long total = (long long)G * a.Npad * (2 * (hd / 8) + (a.DQ - hd) / 8 + a.DV / 8);
+            hipLaunchKernelGGL(sam_attn_split_kernel, dim3(grid_for(total)), dim3(256), 0, stream, qkv, k.qkv_b, Qp, Kp, Vp, a, flag);
+            POPE_TRY(pope_check_launch());
+            const int tpb = 256 / (a.DQ - hd);
+            const dim3 rgrid((a.Npad + tpb - 1) / tpb, a.B * a.nw * a.nw);
+            const size_t lds = size_t(tpb) * dim * sizeof(float);
+            if (hd == 80)
+                hipLaunchKernelGGL(sam_attn_relpos_kernel<80>, rgrid, dim3(256), lds, stream, qkv, k.qkv_b, k.rel_h, k.rel_w, Qp, a, flag);
+            else
+                hipLaunchKernelGGL(sam_attn_relpos_kernel<64>, rgrid, dim3(256), lds, stream, qkv, k.qkv_b, k.rel_h, k.rel_w, Qp, a, flag);
+            POPE_TRY(pope_check_launch());
+        }
         _Float16* att = static_cast<_Float16*>(att_pl);
         if (hd == 80) {
             if (p.nstep == 7) POPE_TRY((launch_attn<7, 5, 3>(p, Qp, Kp, Vp, att, flag, stream)));
