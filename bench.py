@@ -14,7 +14,8 @@ Pairs are independent: every rank works on its own batch (weak scaling, no data-
 the only exchange is the RCCL all_gather of per-pair match counts at the end of each step.
 Rank 0 prints ONE JSON line.  After the timed region the step's own outputs are spot-checked (pairs of the batch
 re-run one at a time must reproduce them bit for bit): `"verified": true`, non-zero exit otherwise.  At N = 1 the
-default run also times a short strict-fp32 leg (`strict_f32`) and the CPU oracle (`cpu_baseline`).
+default run also times a short strict-fp32 leg (`strict_f32`), BASELINE config 5's two encoders (`config5`) and the CPU
+oracle (`cpu_baseline`).
 
 `--workload linemod` (BASELINE config 4): one step = one pass over the 5 796 pair ids of the LINEMOD evaluation list
 (tests/golden/linemod_pairs.json; pixels synthetic, keyed by pair id), sharded contiguously over the ranks, walked
@@ -156,6 +157,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the short strict-fp32 leg of the N = 1 run")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the short BASELINE config 5 leg (DINOv2 ViT-L/14 and the SAM ViT-H image encoder) of the N = 1 run")
     ap.add_argument("--no-verify", action="store_true",
                     help="profiling only: skip the self-check (its batch-1 launches would enter rocprof's per-kernel averages); "
                          "the line then carries \"verified\": null")
@@ -337,6 +340,9 @@ def main():
         result["strict_f32"] = strict_f32_leg(model, pipe, img0, img1, args)
     if rank == 0 and world == 1 and not linemod and args.from_host:
         result["from_host"] = from_host_leg(pipe, args, device)
+    if rank == 0 and world == 1 and not linemod and not args.no_config5:
+        torch.cuda.empty_cache()
+        result["config5"] = config5_leg(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N = 1 only (the other ranks would idle)
         result["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
     if world > 1:
@@ -416,6 +422,64 @@ def roofline_entry(dominant, dom, peak_tflops, mfma_factor, chunk):
                 "region (events on the launch stream); peak = dense MFMA peak of the MFMA dtype "
                 "(MI355X_MICROARCH.md); f16x3 executes 3 MFMA FLOPs per algorithmic FLOP",
     }
+
+
+def config5_leg(device, iters=3):
+    """BASELINE config 5 as two timed forward passes on synthetic weights and inputs (never part of `value`): the
+    DINOv2 backbone swapped to ViT-L/14 on 640 x 480 crops (476 x 630, 16 images per launch sequence) and the SAM
+    ViT-H image encoder on 1024 x 1024 (4 images).  Each figure carries a self-check: finite outputs and image 0 of the
+    batch bit-equal to its own single-image run.  A failure is reported in place, the headline line stands."""
+    from functools import partial
+    from pope_amd import dinov2, synth
+    from pope_amd.sam_encoder import ImageEncoderViT
+
+    def timed(fn, x):
+        fn(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            y = fn(x)
+        e1.record()
+        torch.cuda.synchronize()
+        ok = bool(torch.isfinite(y).all()) and torch.equal(fn(x[:1])[0], y[0])
+        return e0.elapsed_time(e1) / iters, ok
+
+    out = {"note": "synthetic weights and inputs; f16x3 arithmetic; images resident in HBM", "iters": iters}
+    try:
+        m = dinov2.vit_large(patch_size=14, img_size=518, init_values=1e-5, ffn_layer="mlp", block_chunks=0)
+        m.load_state_dict(synth.synthetic_state_dict(seed=0, dim=1024, depth=24), strict=True)
+        m = m.eval().to(device)
+        x = synth.synthetic_images(16, H_IMG, W_IMG, seed=3, device=device)
+        ms, ok = timed(lambda t: m(t, is_training=True)["x_norm_patchtokens"], x)
+        npt = NTOK - 1
+        fl = 2.0 * (1024 * 3 * 196 * npt + 24 * (NTOK * 12 * 1024 * 1024 + 2 * NTOK * NTOK * 1024))
+        out["dinov2_vit_l14"] = {"value": round(16e3 / ms, 1), "unit": "images/s", "batch": 16, "image": [H_IMG, W_IMG],
+                                 "ms_per_image": round(ms / 16, 3), "tflops_algorithmic": round(fl * 16 / ms / 1e9, 1), "verified": ok}
+        del m, x
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001 — reported, not hidden
+        out["dinov2_vit_l14"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        gidx = (7, 15, 23, 31)   # build_sam.py:13-21
+        enc = ImageEncoderViT(depth=32, embed_dim=1280, img_size=1024, mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+                              num_heads=16, patch_size=16, qkv_bias=True, use_rel_pos=True, global_attn_indexes=list(gidx),
+                              window_size=14, out_chans=256)
+        enc.load_state_dict(synth.synthetic_sam_encoder_state_dict(seed=0, global_idx=gidx), strict=True)
+        enc = enc.eval().to(device)
+        x = synth.synthetic_images(4, 1024, 1024, seed=3, device=device)
+        ms, ok = timed(enc, x)
+        n, dim, hd, heads = 4096, 1280, 80, 16
+        lin = n * (768 * dim + 32 * 12 * dim * dim + dim * 256 + 9 * 256 * 256)
+        att = 4 * heads * (n * n * 2 * hd + n * 128 * hd) + 28 * 25 * heads * (196 * 196 * 2 * hd + 196 * 28 * hd)
+        fl = 2.0 * (lin + att)
+        out["sam_vit_h_encoder"] = {"value": round(4e3 / ms, 1), "unit": "images/s", "batch": 4, "image": [1024, 1024],
+                                    "ms_per_image": round(ms / 4, 3), "tflops_algorithmic": round(fl * 4 / ms / 1e9, 1), "verified": ok}
+        del enc, x
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        out["sam_vit_h_encoder"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def strict_f32_leg(model, pipe, img0, img1, args, steps=2):
