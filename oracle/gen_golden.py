@@ -273,6 +273,7 @@ SAM_CASES = {
     "sam_hd80_256": (640, 4, 8, 256, 14, (1, 3), 2, 1),       # head_dim 80 (ViT-H's), grid 16 -> windows padded 16 -> 28
     "sam_hd64_224": (256, 2, 4, 224, 14, (1,), 1, 1),         # head_dim 64 (ViT-B/L's), grid 14 = one exact window
     "sam_vit_h_1024": (1280, 32, 16, 1024, 14, (7, 15, 23, 31), 1, 4),   # build_sam.py:13-21 at full size
+    "sam_vit_b_1024": (768, 12, 12, 1024, 14, (2, 5, 8, 11), 1, 4),      # build_sam.py:36-45 at full size (head_dim 64)
 }
 
 

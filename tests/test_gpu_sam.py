@@ -90,6 +90,14 @@ def test_vit_h_full_size_matches_reference_fixture(hip_lib, golden_dir):
     check_against_fixture(m, x, fx, "sam_vit_h_1024")
 
 
+def test_vit_b_full_size_matches_reference_fixture(hip_lib, golden_dir):
+    """build_sam.py:36-45 at full size: 768-d, 12 heads of 64 — the head_dim-64 instantiations of the attention kernel
+    with padded windows (score depth 96) and 4096-key global blocks (score depth 192)."""
+    fx = np.load(os.path.join(golden_dir, "sam_vit_b_1024.npz"))
+    m, x, _ = build(fx)
+    check_against_fixture(m, x, fx, "sam_vit_b_1024")
+
+
 def test_contract_errors(hip_lib, golden_dir):
     from pope_amd.sam_encoder import ImageEncoderViT
     fx = np.load(os.path.join(golden_dir, "sam_hd64_224.npz"))
