@@ -1,7 +1,7 @@
-"""LoFTR stages either side of the HIP coarse matcher ("adjacent: torch/MIOpen
-first"): local-feature CNN, sinusoidal position code, linear-attention transformer, fine window
-preprocessing and sub-pixel refinement.  These are tensor plumbing on PyTorch-ROCm (MIOpen convolutions,
-rocBLAS linears) around `pope_amd.matcher.CoarseMatching`, which is the hand-written part.
+"""LoFTR stages either side of the HIP coarse matcher: local-feature CNN, sinusoidal
+position code, linear-attention transformer, fine window preprocessing and sub-pixel refinement.  On CUDA tensors every
+stage but the position code is a call into libpope_hip.so (conv.hip, loftr.hip, fine.hip); the torch forms below are
+the fp32 re-run of the f16x3 range guard and the restatement the GPU tests compare against (`use_hip = False`).
 
 Every module keeps the reference's parameter names and shapes so that `weights/matcher.pth` loads with
 strict=True (211 keys: backbone.* 107, loftr_coarse.* 80, fine_preprocess.* 4, loftr_fine.* 20), but the
@@ -20,6 +20,21 @@ import torch.nn.functional as F
 
 
 # ------------------------------------------------------------------------------------------------ CNN
+
+# While `Matcher` captures its front end into a HIP graph nothing may synchronise: the range-flag words of the captured
+# launches are collected here and read by the Matcher after each replay (matcher.py:_features_graphed).
+DEFERRED_FLAGS = None
+
+
+def _read_flags(flags):
+    """OR of f16x3 range-guard words (int32[1] device tensors): one synchronisation — or 0 now and the check deferred
+    to the capturing Matcher."""
+    if DEFERRED_FLAGS is not None and torch.cuda.is_current_stream_capturing():
+        DEFERRED_FLAGS.extend(flags)
+        return 0
+    return int(torch.stack(list(flags)).max()) if len(flags) > 1 else int(flags[0].item())
+
+
 def _fold_bn(conv_w, bn):
     """Filter and bias of conv -> BatchNorm(eval) as one convolution."""
     g = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
@@ -159,7 +174,7 @@ class ResNetFPN_8_2(nn.Module):
             _lib.check(_lib.lib().pope_resnetfpn_forward_f32(
                 C.byref(w), C.c_void_p(x.data_ptr()), n, H, W, C.c_void_p(out_c.data_ptr()), C.c_void_p(out_f.data_ptr()),
                 C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(flag.data_ptr()), _lib.stream_of(dev)), "pope_resnetfpn_forward_f32")
-        bits = int(flag.item())
+        bits = _read_flags([flag])
         if bits:
             import warnings
             warnings.warn(f"pope_amd: f16x3 range contract breached in the LoFTR backbone ({_lib.describe_range_bits(bits)}); "
@@ -386,7 +401,7 @@ class LocalFeatureTransformer(nn.Module):
             else:
                 flags.append(layer.update_(f0, f1, ws))
                 flags.append(layer.update_(f1, f0, ws))
-        bits = int(torch.stack(flags).max())   # one synchronisation per transformer
+        bits = _read_flags(flags)   # one synchronisation per transformer
         if bits:
             import warnings
             warnings.warn(f"pope_amd: f16x3 range contract breached in the LoFTR transformer ({_lib.describe_range_bits(bits)}); "

@@ -162,6 +162,74 @@ class Matcher(nn.Module):
         self.fine_preprocess = loftr.FinePreprocess(config)
         self.loftr_fine = loftr.LocalFeatureTransformer(config["fine"])
         self.fine_matching = loftr.FineMatching()
+        # use_graph = True: the shape-static front of the forward pass (CNN, position code, coarse transformer: ~250 kernel
+        # launches at the drivers' batch of three pairs) is replayed from a captured HIP graph from the third call with
+        # the same input shapes on.  Same kernels, same order: bit-identical to the eager launches (tests/test_gpu_loftr.py).
+        # Off by default because it buys nothing on this path: measured 4.23 -> 4.22 ms per 3-pair call, 17.32 -> 17.27 ms at
+        # 24 pairs, driver step 7.34 -> 7.16 ms (scripts/loftr_time.py) — the C-side launch loops already keep the GPU fed,
+        # the time is the small-grid kernels themselves.
+        self.use_graph = False
+        self._graphs = {}
+
+    def _features(self, im0, im1):
+        """matcher.py:46-60: (feat_c0, feat_c1) after the coarse transformer [n, L, 256] and the fine maps (feat_f0, feat_f1)."""
+        n = im0.size(0)
+        if im0.shape[2:] == im1.shape[2:]:  # one CNN launch sequence for both images (matcher.py:46-48)
+            feats_c, feats_f = self.backbone(torch.cat([im0, im1], 0))
+            (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(n), feats_f.split(n)
+        else:
+            (feat_c0, feat_f0), (feat_c1, feat_f1) = self.backbone(im0), self.backbone(im1)
+        hw_c = (feat_c0.shape[2:], feat_c1.shape[2:])
+        feat_c0 = self.pos_encoding(feat_c0).flatten(2).transpose(1, 2)   # 'n c h w -> n (h w) c'
+        feat_c1 = self.pos_encoding(feat_c1).flatten(2).transpose(1, 2)
+        feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1)
+        return feat_c0, feat_c1, feat_f0, feat_f1, hw_c
+
+    def _features_graphed(self, im0, im1):
+        """`_features` through a HIP graph per (shapes, device): call 1 runs eagerly (builds every weight cache, checks
+        the range flags), call 2 captures, later calls copy the inputs into the graph's static buffers and replay.
+        The f16x3 range flags of the captured launches are read after the replay (one synchronisation, where the eager
+        path has two); a raised flag retires the graph and the eager path — with its warnings and fp32 re-runs — takes over."""
+        from . import loftr
+        if not (self.use_graph and im0.size(0) > 0 and im0.dtype == torch.float32 and im1.dtype == torch.float32
+                and not torch.cuda.is_current_stream_capturing()):
+            return self._features(im0, im1)
+        key = (tuple(im0.shape), tuple(im1.shape), im0.device.index, self.backbone.conv1.weight.data_ptr())
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= 16:   # every graph owns its workspaces: keep the set small
+                self._graphs.clear()
+            self._graphs[key] = {}
+            return self._features(im0, im1)
+        if ent.get("retired"):
+            return self._features(im0, im1)
+        if "graph" not in ent:
+            s0, s1 = im0.clone(), im1.clone()
+            graph = torch.cuda.CUDAGraph()
+            loftr.DEFERRED_FLAGS = []
+            try:
+                with torch.cuda.graph(graph):
+                    outs = self._features(s0, s1)
+                flags = loftr.DEFERRED_FLAGS
+            except Exception:   # noqa: BLE001 — a capture the runtime refuses is not an error of the forward pass
+                ent["retired"] = True
+                loftr.DEFERRED_FLAGS = None
+                torch.cuda.synchronize(im0.device)
+                return self._features(im0, im1)
+            finally:
+                loftr.DEFERRED_FLAGS = None
+            ent.update(graph=graph, s0=s0, s1=s1, outs=outs, flags=flags)
+        ent["s0"].copy_(im0)
+        ent["s1"].copy_(im1)
+        ent["graph"].replay()
+        if ent["flags"] and int(torch.stack(ent["flags"]).max()):
+            ent["retired"] = True
+            return self._features(im0, im1)
+        return ent["outs"]
+
+    def _apply(self, fn, *a, **k):
+        self._graphs = {}
+        return super()._apply(fn, *a, **k)
 
     @torch.no_grad()
     def forward(self, data, only_att_fea=False):
@@ -172,18 +240,10 @@ class Matcher(nn.Module):
             raise NotImplementedError("pope_amd: padding masks are a training-time path (matcher.py:62-64)")
         n = im0.size(0)
         data.update({"bs": n, "hw0_i": im0.shape[2:], "hw1_i": im1.shape[2:]})
-        if data["hw0_i"] == data["hw1_i"]:  # one CNN launch sequence for both images (matcher.py:46-48)
-            feats_c, feats_f = self.backbone(torch.cat([im0, im1], 0))
-            (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(n), feats_f.split(n)
-        else:
-            (feat_c0, feat_f0), (feat_c1, feat_f1) = self.backbone(im0), self.backbone(im1)
-        data.update({"hw0_c": feat_c0.shape[2:], "hw1_c": feat_c1.shape[2:],
-                     "hw0_f": feat_f0.shape[2:], "hw1_f": feat_f1.shape[2:]})
-        feat_c0 = self.pos_encoding(feat_c0).flatten(2).transpose(1, 2)   # 'n c h w -> n (h w) c'
-        feat_c1 = self.pos_encoding(feat_c1).flatten(2).transpose(1, 2)
-        feat_c0, feat_c1 = self.loftr_coarse(feat_c0, feat_c1)
-        if only_att_fea:
-            return feat_c0, feat_c1
+        feat_c0, feat_c1, feat_f0, feat_f1, (hw0_c, hw1_c) = self._features_graphed(im0, im1)
+        data.update({"hw0_c": hw0_c, "hw1_c": hw1_c, "hw0_f": feat_f0.shape[2:], "hw1_f": feat_f1.shape[2:]})
+        if only_att_fea:   # the caller keeps these: never hand out a graph's static buffers
+            return feat_c0.clone(), feat_c1.clone()
         self.coarse_matching(feat_c0, feat_c1, data)
         win0, win1 = self.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data)
         if win0.size(0) != 0:
@@ -194,4 +254,11 @@ class Matcher(nn.Module):
         # src/matcher/matcher.py:81-85: the keys are renamed IN THE CALLER'S dict (observable afterwards)
         for old in [k for k in state_dict if k.startswith("matcher.")]:
             state_dict[old[len("matcher."):]] = state_dict.pop(old)
-        return super().load_state_dict(state_dict, *args, **kwargs)
+        out = super().load_state_dict(state_dict, *args, **kwargs)
+        for m in self.modules():   # parameters were overwritten in place: drop every derived cache (folded BatchNorm, weight
+            if getattr(m, "_hip", None) is not None:   # planes — their keys are data pointers — and the captured graphs)
+                m._hip = None
+            if getattr(m, "_folded", None) is not None:
+                m._folded = None
+        self._graphs = {}
+        return out

@@ -10,13 +10,16 @@ dev = torch.device("cuda:0")
 m = Matcher(default_cfg).eval(); m.load_state_dict(synth.synthetic_matcher_state_dict(0)); m = m.to(dev)
 vit = load_dinov2_model(state_dict=synth.synthetic_state_dict(0)).to(dev)
 i0, i1 = (t.to(dev) for t in synth.synthetic_gray_pairs(3, 256, 256, seed=21))
-for n in (3, 24):
-    a, b = i0.repeat(n // 3, 1, 1, 1), i1.repeat(n // 3, 1, 1, 1)
-    for _ in range(3): m({"image0": a, "image1": b})
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(10): d = {"image0": a, "image1": b}; m(d)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-    print(f"Matcher batch {n} x 256x256: {dt*1e3:.2f} ms per call = {n/dt:.0f} LoFTR pairs/s, {len(d['b_ids'])} matches")
+for graph in (False, True):   # eager launches against the HIP-graph replay of the front end
+    m.use_graph = graph
+    for n in (3, 24):
+        a, b = i0.repeat(n // 3, 1, 1, 1), i1.repeat(n // 3, 1, 1, 1)
+        for _ in range(3): m({"image0": a, "image1": b})
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): d = {"image0": a, "image1": b}; m(d)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+        print(f"Matcher batch {n} x 256x256 ({'graph' if graph else 'eager'}): {dt*1e3:.2f} ms per call = {n/dt:.0f} LoFTR pairs/s, "
+              f"{len(d['b_ids'])} matches")
 for n in (6, 48):   # the CNN alone: HIP planes-GEMM convolutions against the torch / MIOpen form
     x = torch.cat([i0, i1], 0).repeat(n // 6, 1, 1, 1)
     for hip in (True, False):
@@ -28,8 +31,11 @@ for n in (6, 48):   # the CNN alone: HIP planes-GEMM convolutions against the to
         print(f"backbone {n} x 256x256 ({'HIP' if hip else 'MIOpen'}): {dt*1e3:.2f} ms = {n * 63.1 / dt / 1e3:.1f} TFLOP/s")
 m.backbone.use_hip = True
 case = [t.to(dev) for t in synth.synthetic_driver_case()]
-for _ in range(3): locate_and_match(vit, m, *case)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10): out = locate_and_match(vit, m, *case)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-print(f"driver step (8 proposals: batched DINOv2 vote + one 3-pair Matcher call): {dt*1e3:.2f} ms -> {1/dt:.1f} queries/s")
+for graph in (False, True):
+    m.use_graph = graph
+    for _ in range(3): locate_and_match(vit, m, *case)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): out = locate_and_match(vit, m, *case)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    print(f"driver step (8 proposals: batched DINOv2 vote + one 3-pair Matcher call; {'graph' if graph else 'eager'}): "
+          f"{dt*1e3:.2f} ms -> {1/dt:.1f} queries/s")

@@ -112,6 +112,45 @@ def test_only_att_fea_and_feature_parity(dev, golden_dir):
     np.testing.assert_allclose(bf[:1, ::4, ::8, ::8].cpu().numpy(), fx["backbone_f"], **FEAT_TOL)
 
 
+def test_graph_replay_is_bit_identical_to_eager_launches(dev, golden_dir):
+    """The Matcher's shape-static front end (CNN, position code, coarse transformer) replayed from a captured HIP graph
+    (call 1 eager, call 2 captures, calls 3+ replay) publishes exactly what the eager launches publish — on the
+    captured input and on new inputs of the same shape — and a load_state_dict drops the graphs."""
+    fx = np.load(os.path.join(golden_dir, "loftr_256_lowthr.npz"))
+    m, e = build(fx["thr"], dev), build(fx["thr"], dev)
+    m.use_graph, e.use_graph = True, False
+    i0, i1 = inputs(fx, dev)
+    keys = ("conf_matrix", "b_ids", "i_ids", "j_ids", "mconf", "mkpts0_c", "mkpts1_c", "expec_f", "mkpts0_f", "mkpts1_f")
+
+    def run(model, a, b):
+        d = {"image0": a, "image1": b}
+        model(d)
+        return d
+
+    want = run(e, i0, i1)
+    for call in range(4):
+        got = run(m, i0, i1)
+        for k in keys:
+            assert torch.equal(got[k], want[k]), (call, k)
+    ents = [v for v in m._graphs.values() if "graph" in v]
+    assert len(ents) == 1 and not ents[0].get("retired") and len(ents[0]["flags"]) >= 2
+    j0, j1 = i1.flip(0).contiguous(), i0.flip(0).contiguous()        # new pixels, same shapes: replay with fresh inputs
+    want2, got2 = run(e, j0, j1), run(m, j0, j1)
+    assert len(want2["b_ids"]) > 0
+    for k in keys:
+        assert torch.equal(got2[k], want2[k]), k
+    f0, f1 = m({"image0": i0, "image1": i1}, only_att_fea=True)     # copies, not the graph's static buffers
+    g0, _ = m({"image0": j0, "image1": j1}, only_att_fea=True)
+    assert not torch.equal(f0, g0) and torch.equal(f0, e({"image0": i0, "image1": i1}, only_att_fea=True)[0])
+    # a range-guard event inside the replayed launches retires the graph and the eager path (warning, fp32 re-run) takes over
+    with pytest.warns(UserWarning, match="range contract"):
+        big = run(m, i0 * 3.0e4, i1)
+    assert any(v.get("retired") for v in m._graphs.values()) and torch.isfinite(big["conf_matrix"]).all()
+    from pope_amd import synth
+    m.load_state_dict(synth.synthetic_matcher_state_dict(seed=0), strict=True)
+    assert m._graphs == {}
+
+
 def test_no_coarse_match_short_circuit(dev):
     """thr above every confidence: M = 0, fine stage skipped, *_f alias *_c (fine_matching.py:33-41)."""
     from pope_amd import synth
