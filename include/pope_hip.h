@@ -50,7 +50,7 @@ enum {
  *                      (v_mfma_f32_16x16x32_f16 in the GEMMs, v_mfma_f32_32x32x16_f16 in attention) per product
  *                      block on the matrix cores: same or smaller error than the fp32 chain inside the range
  *                      contract below (measured against fp64), 2.3x faster end to end. */
-enum { POPE_PREC_F32_MFMA = 0, POPE_PREC_F16X3 = 1 };
+enum { POPE_PREC_F32_MFMA = 0, POPE_PREC_F16X3 = 1, POPE_PREC_F16 = 2 /* SAM encoder only: plain f16 operands, see there */ };
 /* bits of a range_flag word: which f16x3 producer saw a value out of range */
 enum { POPE_RANGE_PATCH = 1, POPE_RANGE_LAYERNORM = 2, POPE_RANGE_QKV = 4, POPE_RANGE_GELU = 8, POPE_RANGE_MATCH = 16,
        POPE_RANGE_INPUT = 32 };
@@ -304,6 +304,9 @@ typedef struct pope_sam_block_weights {
 } pope_sam_block_weights;
 typedef struct pope_sam_encoder_weights {
     int img, patch, dim, depth, heads, hidden, out_chans, window;
+    int precision;   /* POPE_PREC_F16X3, or POPE_PREC_F16: BASELINE config 5's "fp16" — every `*_wp` is then a plain f16
+                      * row-major matrix (value * 256) and every contraction ONE f16 MFMA per product with fp32
+                      * accumulation; residual stream, softmax, LayerNorm statistics and GELU stay fp32 */
     const void* patch_wp; const float* patch_b;
     const float* pos;
     const float* ones;

@@ -44,14 +44,14 @@ class SamBlockWeights(C.Structure):
 
 
 class SamEncoderWeights(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("img", "patch", "dim", "depth", "heads", "hidden", "out_chans", "window")] + [
+    _fields_ = [(n, C.c_int) for n in ("img", "patch", "dim", "depth", "heads", "hidden", "out_chans", "window", "precision")] + [
         ("patch_wp", C.c_void_p), ("patch_b", C.c_void_p), ("pos", C.c_void_p), ("ones", C.c_void_p),
         ("blocks_host", C.POINTER(SamBlockWeights)), ("neck0_wp", C.c_void_p), ("neck1_w", C.c_void_p), ("neck1_b", C.c_void_p),
         ("neck2_wp", C.c_void_p), ("neck3_w", C.c_void_p), ("neck3_b", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/pope_hip.h
-PREC_F32_MFMA, PREC_F16X3 = 0, 1
+PREC_F32_MFMA, PREC_F16X3, PREC_F16 = 0, 1, 2
 PLANES_ACT_SCALE, PLANES_W_SCALE = 8.0, 256.0
 PRECISIONS = {"f32": PREC_F32_MFMA, "f16x3": PREC_F16X3}
 c_uint_p = C.POINTER(C.c_uint)

@@ -563,7 +563,7 @@ static bool sam_params(const pope_sam_encoder_weights* w, int B, SamEncParams& q
     if (!w || !w->blocks_host || w->depth <= 0 || w->depth > 64) return false;
     q = SamEncParams{};
     q.B = B; q.img = w->img; q.patch = w->patch; q.dim = w->dim; q.depth = w->depth; q.heads = w->heads; q.hidden = w->hidden;
-    q.out_chans = w->out_chans; q.window = w->window;
+    q.out_chans = w->out_chans; q.window = w->window; q.precision = w->precision;
     q.patch_wp = w->patch_wp; q.patch_b = w->patch_b; q.pos = w->pos; q.ones = w->ones;
     q.neck0_wp = w->neck0_wp; q.neck1_w = w->neck1_w; q.neck1_b = w->neck1_b; q.neck2_wp = w->neck2_wp;
     q.neck3_w = w->neck3_w; q.neck3_b = w->neck3_b;

@@ -867,7 +867,7 @@ static bool use_mfma32() {
 
 template <int EPI, bool OUT_PLANES>
 int launch_planes(const GemmParams& g, hipStream_t stream) {
-    if (!use_mfma32()) return pope_launch_planes16(g, stream);
+    if (g.plain || !use_mfma32()) return pope_launch_planes16(g, stream);   // the single-product mode lives in gemm_planes.hip only
     static const int force = getenv("POPE_GEMM_BM") ? atoi(getenv("POPE_GEMM_BM")) : 0;  // dev switch: 128 or 256
     // Measured (DESIGN.md §4 finding 6): the 256-row kernel moves 25 % fewer LDS store bytes per MFMA and is 2-5 %
     // faster on QKV / FC1 in isolation, but inside the model (planes outputs, neighbours' cache state) the 128-row

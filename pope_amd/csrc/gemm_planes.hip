@@ -57,7 +57,12 @@ __device__ __forceinline__ f32x2 gelu_erf_pair(f32x2 x) {
     return __builtin_elementwise_fma(relu, __builtin_elementwise_fma(q, f32x2{-2.f, -2.f}, f32x2{1.f, 1.f}), x * q);
 }
 
-template <int EPI, bool OUT_PLANES, bool CONV = false>
+// PLAIN (GemmParams::plain): single-product f16 arithmetic on the same loader, LDS layout and epilogues.  An f16
+// row-major tensor [rows, 2 ld] IS a planes tensor [rows, ld] whose "lo" half of a 128-byte chunk holds the NEXT 32
+// columns instead of the residuals of the first 32; a K-step then covers 64 real columns with 32 MFMAs (hi.hi + lo.lo)
+// instead of 32 columns with 48.  K, lda, ldw (and ldc of a planes output) count 64-bit column pairs, N / bias /
+// residual stay in real columns; a planes output is written as f16 row-major (value * 8).  BASELINE config 5's "fp16".
+template <int EPI, bool OUT_PLANES, bool CONV = false, bool PLAIN = false>
 __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmParams g, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* lds = reinterpret_cast<_Float16*>(smem);
@@ -373,7 +378,11 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
                 } else {
                     v = res[i] + v * gamma + bias;
                 }
-                if constexpr (OUT_PLANES) {
+                if constexpr (OUT_PLANES && PLAIN) {   // f16 row-major, value * 8
+                    pope_amax4x2(amax, v);
+                    const f16x4 h = __builtin_convertvector(v * A_SCALE, f16x4);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rc, col_ok ? off + unsigned(col) * 2u : DROP, 0, 2);
+                } else if constexpr (OUT_PLANES) {
                     f16x4 hi, lo;
                     pope_amax4x2(amax, v);
                     pope_split4(v * A_SCALE, hi, lo);
@@ -413,35 +422,48 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
     auto item = [&](int s, u32x4 (&nx)[NLD]) {
         Frags f;
         const _Float16* S = lds + (s & 1) * STAGE;
+        // first batch of fragment reads = the operands of the first product (f16x3: W lo, A hi; PLAIN: W hi, A hi)
+        constexpr int W_FIRST = PLAIN ? 0 : 32, W_SECOND = PLAIN ? 32 : 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            f.wl[t] = *reinterpret_cast<const f16x8*>(S + 32 + w_off + t * 16 * ROWH);
+            (PLAIN ? f.wh[t] : f.wl[t]) = *reinterpret_cast<const f16x8*>(S + W_FIRST + w_off + t * 16 * ROWH);
             f.ah[t] = *reinterpret_cast<const f16x8*>(S + a_off + t * 16 * ROWH);
         }
         write_stage((s + 1) & 1, nx);
         load_next(nx);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            f.wh[t] = *reinterpret_cast<const f16x8*>(S + w_off + t * 16 * ROWH);
+            (PLAIN ? f.wl[t] : f.wh[t]) = *reinterpret_cast<const f16x8*>(S + W_SECOND + w_off + t * 16 * ROWH);
             f.al[t] = *reinterpret_cast<const f16x8*>(S + 32 + a_off + t * 16 * ROWH);
         }
         // accumulators hold C^T (A-operand = W fragment, B-operand = A fragment); small terms first; term-major: an
         // accumulator is touched again only 16 MFMAs later
+        if constexpr (PLAIN) {   // "lo" = the second 32 columns of the K-step: two plain products
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(f.wl[ni], f.ah[mi], acc[mi][ni]);
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(f.wh[ni], f.ah[mi], acc[mi][ni]);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(f.wh[ni], f.al[mi], acc[mi][ni]);
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(f.wl[ni], f.al[mi], acc[mi][ni]);
+        } else {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(f.wh[ni], f.ah[mi], acc[mi][ni]);
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(f.wl[ni], f.ah[mi], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(f.wh[ni], f.al[mi], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(f.wh[ni], f.ah[mi], acc[mi][ni]);
+        }
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // wl, ah
 #pragma unroll
-        for (int i = 0; i < 48; ++i) {
+        for (int i = 0; i < (PLAIN ? 32 : 48); ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if (i < NLD) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             if (i >= 4 && i < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // wh, al
@@ -464,13 +486,13 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
     }
 }
 
-template <int EPI, bool OUT_PLANES, bool CONV = false>
+template <int EPI, bool OUT_PLANES, bool CONV = false, bool PLAIN = false>
 int launch16(const GemmParams& g, hipStream_t stream, int nbatch = 1) {
     static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
-    if (!pope_opt_in_lds(gemm_planes16_kernel<EPI, OUT_PLANES, CONV>, P16_LDS_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
+    if (!pope_opt_in_lds(gemm_planes16_kernel<EPI, OUT_PLANES, CONV, PLAIN>, P16_LDS_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
     const int tiles = nbatch * ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     const int slots = 2 * pope_cu_count();   // two resident workgroups per CU (2 x 80 KB LDS)
-    hipLaunchKernelGGL((gemm_planes16_kernel<EPI, OUT_PLANES, CONV>), dim3(tiles < slots ? tiles : slots), dim3(THREADS), P16_LDS_BYTES,
+    hipLaunchKernelGGL((gemm_planes16_kernel<EPI, OUT_PLANES, CONV, PLAIN>), dim3(tiles < slots ? tiles : slots), dim3(THREADS), P16_LDS_BYTES,
                        stream, g, tiles);
     return pope_check_launch();
 }
@@ -480,6 +502,15 @@ int launch16(const GemmParams& g, hipStream_t stream, int nbatch = 1) {
 // argument checks are the callers' (gemm_f16x3.hip: pope_launch_gemm_nt_f16x3_planes / pope_launch_sim_f16x3_planes)
 int pope_launch_planes16(const GemmParams& g, hipStream_t stream) {
     const bool out_planes = g.c_pl != nullptr;
+    if (g.plain) {   // single-product f16 (SAM encoder, precision "f16"): the four forms that path uses
+        if (g.epilogue == EPI_BIAS && !out_planes) return launch16<EPI_BIAS, false, false, true>(g, stream);
+        if (g.epilogue == EPI_BIAS_GELU && out_planes) return launch16<EPI_BIAS_GELU, true, false, true>(g, stream);
+        if (g.epilogue == EPI_BIAS_LS_RES && !out_planes) return launch16<EPI_BIAS_LS_RES, false, false, true>(g, stream);
+        if (g.epilogue == EPI_CONV && !out_planes && g.conv_cch > 0 && g.K == 9 * 32 * g.conv_cch && g.lda == 32 * g.conv_cch &&
+            g.conv_wp >= 3)
+            return launch16<EPI_CONV, false, true, true>(g, stream);
+        return POPE_ERR_ARG;
+    }
     switch (g.epilogue) {
         case EPI_BIAS: return out_planes ? launch16<EPI_BIAS, true>(g, stream) : launch16<EPI_BIAS, false>(g, stream);
         case EPI_BIAS_GELU: return out_planes ? launch16<EPI_BIAS_GELU, true>(g, stream) : launch16<EPI_BIAS_GELU, false>(g, stream);

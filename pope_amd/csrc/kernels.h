@@ -70,6 +70,10 @@ struct GemmParams {
     int ldres_pl;
     float act_slope;
     int conv_cch, conv_wp;
+    // plain != 0 (gemm_planes.hip only): single-product f16 arithmetic.  a_pl / w_pl (and c_pl) are f16 ROW-MAJOR tensors
+    // (value * scale); K, lda, ldw and a planes output's ldc are given in 64-bit column PAIRS (= real columns / 2, so
+    // that a row's pitch is still ld * 4 bytes); N, ldc of an fp32 output, bias, gamma and res stay in real columns.
+    int plain;
     // patch-embed gather (EPI_POSB)
     const float* posb;   // [ntok, N]: row 0 = cls_token + pos[0]; row n = conv bias + pos[n]
     int ntok, img_h, img_w, patch, grid_w;
@@ -234,6 +238,7 @@ struct SamEncParams {
     const float* image;   // [B, 3, img, img] fp32
     float* out;           // [B, out_chans, g, g] fp32, g = img / patch
     int B, img, patch, dim, depth, heads, hidden, out_chans, window;
+    int precision;        // POPE_PREC_F16X3 (weights = planes) | POPE_PREC_F16 (weights = f16 row-major, value * 256)
     const void* patch_wp; const float* patch_b;   // [dim, 3 patch^2], [dim]
     const float* pos;                             // [g g, dim] or null (use_abs_pos = False)
     const float* ones;                            // [dim] of 1.0f (no LayerScale in this ViT)

@@ -48,6 +48,7 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
 
 // ---- patch embed operand: image [B, 3, S, S] -> activation planes [B * g * g, 3 * P * P], k = (c, ky, kx) as
 // Conv2d's weight.reshape(dim, -1) (image_encoder.py:385-393); P % 8 == 0
+template <bool PLAIN>
 __global__ __launch_bounds__(256) void sam_im2col_kernel(const float* __restrict__ img, _Float16* __restrict__ out, int B, int S,
                                                          int P, unsigned* range_flag) {
     const int g = S / P, K = 3 * P * P, pieces = K / 8;
@@ -63,12 +64,17 @@ __global__ __launch_bounds__(256) void sam_im2col_kernel(const float* __restrict
         amax = pope_amax4(pope_amax4(amax, v0), v1);
         const float s8 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
         if (!(s8 == s8)) amax = INFINITY;   // NaN (fmax drops it)
-        f16x4 h0, l0, h1, l1;
-        pope_split4(v0 * A_SCALE, h0, l0);
-        pope_split4(v1 * A_SCALE, h1, l1);
-        _Float16* o = out + (size_t)row * 2 * K + (k >> 5) * 64 + (k & 31);
-        *reinterpret_cast<f16x8*>(o) = cat(h0, h1);
-        *reinterpret_cast<f16x8*>(o + 32) = cat(l0, l1);
+        if constexpr (PLAIN) {   // f16 row-major
+            *reinterpret_cast<f16x8*>(out + (size_t)row * K + k) =
+                cat(__builtin_convertvector(v0 * A_SCALE, f16x4), __builtin_convertvector(v1 * A_SCALE, f16x4));
+        } else {
+            f16x4 h0, l0, h1, l1;
+            pope_split4(v0 * A_SCALE, h0, l0);
+            pope_split4(v1 * A_SCALE, h1, l1);
+            _Float16* o = out + (size_t)row * 2 * K + (k >> 5) * 64 + (k & 31);
+            *reinterpret_cast<f16x8*>(o) = cat(h0, h1);
+            *reinterpret_cast<f16x8*>(o + 32) = cat(l0, l1);
+        }
     }
     pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax * A_SCALE < POPE_F16_OVERFLOW));
 }
@@ -100,9 +106,12 @@ __device__ __forceinline__ const float* sam_src(const float* qkv, const float* q
     return (y < a.g && x < a.g) ? qkv + ((size_t)b * a.g * a.g + (size_t)y * a.g + x) * 3 * a.dim + col : qkv_bias + col;
 }
 
+template <bool PLAIN>
 __global__ __launch_bounds__(256) void sam_attn_split_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                              _Float16* __restrict__ Qp, _Float16* __restrict__ Kp,
                                                              _Float16* __restrict__ Vp, AttnGeom a, unsigned* range_flag) {
+    // row pitches (halves): PLAIN rows carry no lo halves
+    const int q_row = PLAIN ? a.DQ : 2 * a.DQ, k_row = PLAIN ? a.DQ : a.DQ + a.HDP, v_row = PLAIN ? a.DV : 2 * a.DV;
     const int hp = a.hd / 8, jp = (a.DQ - a.hd) / 8, vp = a.DV / 8;
     const int per_row = 2 * hp + jp + vp;   // q pieces | k pieces | one-hot pieces | v pieces
     const int G = a.B * a.nw * a.nw * a.heads;
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256) void sam_attn_split_kernel(const float* __rest
             f16x8 v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (live && (c0 + e == kh || c0 + e == a.ws + kw)) ? _Float16(1.0f) : _Float16(0.0f);
-            *reinterpret_cast<f16x8*>(Kp + (size_t)row * (a.DQ + a.HDP) + a.hd + c0) = v;
+            *reinterpret_cast<f16x8*>(Kp + (size_t)row * k_row + a.hd + c0) = v;
             continue;
         }
         const int which = piece < hp ? 0 : (piece < 2 * hp ? 1 : 2);
@@ -136,23 +145,27 @@ __global__ __launch_bounds__(256) void sam_attn_split_kernel(const float* __rest
         amax = pope_amax4(pope_amax4(amax, v0), v1);
         const float s8 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
         if (!(s8 == s8)) amax = INFINITY;
-        f16x4 h0, l0, h1, l1;
-        pope_split4(v0, h0, l0);
-        pope_split4(v1, h1, l1);
         _Float16* hi_dst;
         _Float16* lo_dst;
-        if (which == 0) { hi_dst = Qp + (size_t)row * 2 * a.DQ + c0; lo_dst = hi_dst + a.DQ; }
-        else if (which == 1) { hi_dst = Kp + (size_t)row * (a.DQ + a.HDP) + c0; lo_dst = hi_dst + a.DQ; }
-        else { hi_dst = Vp + (size_t)row * 2 * a.DV + c0; lo_dst = hi_dst + a.DV; }
-        *reinterpret_cast<f16x8*>(hi_dst) = cat(h0, h1);
-        *reinterpret_cast<f16x8*>(lo_dst) = cat(l0, l1);
+        if (which == 0) { hi_dst = Qp + (size_t)row * q_row + c0; lo_dst = hi_dst + a.DQ; }
+        else if (which == 1) { hi_dst = Kp + (size_t)row * k_row + c0; lo_dst = hi_dst + a.DQ; }
+        else { hi_dst = Vp + (size_t)row * v_row + c0; lo_dst = hi_dst + a.DV; }
+        if constexpr (PLAIN) {
+            *reinterpret_cast<f16x8*>(hi_dst) = cat(__builtin_convertvector(v0, f16x4), __builtin_convertvector(v1, f16x4));
+        } else {
+            f16x4 h0, l0, h1, l1;
+            pope_split4(v0, h0, l0);
+            pope_split4(v1, h1, l1);
+            *reinterpret_cast<f16x8*>(hi_dst) = cat(h0, h1);
+            *reinterpret_cast<f16x8*>(lo_dst) = cat(l0, l1);
+        }
     }
     pope_range_flag(range_flag, POPE_RANGE_QKV, !(amax < POPE_F16_OVERFLOW));
 }
 
 // Rh / Rw: [ws][ws][hd] fp32, the gathered tables get_rel_pos returns (image_encoder.py:288-316; host, once per model).
 // Workgroup = TPB = 256 / JT tokens of one window batch (JT = DQ - hd = 32 or 128 columns: 2 ws live ones, zeros behind).
-template <int HD>
+template <int HD, bool PLAIN>
 __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                               const float* __restrict__ Rh, const float* __restrict__ Rw,
                                                               _Float16* __restrict__ Qp, AttnGeom a, unsigned* range_flag) {
@@ -198,9 +211,9 @@ __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __res
             amax = fmaxf(amax, fabsf(acc));
             if (!(acc == acc)) amax = INFINITY;
             const _Float16 hi = _Float16(acc);
-            _Float16* dst = Qp + ((size_t)(wb * a.heads + head) * a.Npad + n) * 2 * a.DQ + HD + j;
+            _Float16* dst = Qp + ((size_t)(wb * a.heads + head) * a.Npad + n) * (PLAIN ? a.DQ : 2 * a.DQ) + HD + j;
             dst[0] = hi;
-            dst[a.DQ] = _Float16(acc - float(hi));
+            if constexpr (!PLAIN) dst[a.DQ] = _Float16(acc - float(hi));
         }
     }
     pope_range_flag(range_flag, POPE_RANGE_QKV, !(amax < POPE_F16_OVERFLOW));
@@ -213,25 +226,28 @@ constexpr int KT = 32;
 // blocks, where 16 workgroups walk the same 4096 keys.  4 for the window blocks: a (window, head) is only seven tiles
 // long, and two resident workgroups per CU overlap one's prologue / epilogue with the other's tiles (measured at
 // ViT-H: +0.7 % on the whole encoder against 8 everywhere, -0.8 % with 4 everywhere; POPE_SAM_ATTN_WAVES forces one).
-template <int NSTEP, int HSTEP, int DVT, int WAVES>
+// PLAIN: single-product f16 arithmetic (precision "f16"): the operands have no lo planes (rows are [DQ] / [DV] halves),
+// one MFMA per step, P converted once, output f16 row-major.
+template <int NSTEP, int HSTEP, int DVT, int WAVES, bool PLAIN>
 struct AttnCfg {
     static constexpr int NT = 64 * WAVES, QB = 32 * WAVES;
     static constexpr int DQ = 16 * NSTEP, HDP = 16 * HSTEP, DV = 32 * DVT;
-    static constexpr int KST = DQ + 8, KLST = HDP + 8, VST = DV + 8;   // LDS row strides (halves): odd multiples of 16 bytes
-    static constexpr int K_UNITS_ROW = (DQ + HDP) / 8, V_UNITS_ROW = 2 * DV / 8;   // 16-byte pieces per global row
+    static constexpr int KST = DQ + 8, KLST = PLAIN ? 0 : HDP + 8, VST = DV + 8;   // LDS row strides (halves): odd multiples of 16 bytes
+    static constexpr int Q_ROW = PLAIN ? DQ : 2 * DQ, K_ROW = PLAIN ? DQ : DQ + HDP, V_ROW = PLAIN ? DV : 2 * DV;   // global rows (halves)
+    static constexpr int K_UNITS_ROW = K_ROW / 8, V_UNITS_ROW = V_ROW / 8;   // 16-byte pieces per global row
     static constexpr int K_UNITS = KT * K_UNITS_ROW, V_UNITS = KT * V_UNITS_ROW;
     static constexpr int KP = (K_UNITS + NT - 1) / NT, VP = (V_UNITS + NT - 1) / NT;
     static constexpr int OST = HDP + 4;                                 // epilogue staging row (floats)
-    static constexpr size_t STAGE_BYTES = size_t(KT) * (KST + KLST + 2 * VST) * sizeof(_Float16);
+    static constexpr size_t STAGE_BYTES = size_t(KT) * (KST + KLST + (PLAIN ? 1 : 2) * VST) * sizeof(_Float16);
     static constexpr size_t EPI_BYTES = size_t(QB) * OST * sizeof(float);
     static constexpr size_t LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
 
-template <int NSTEP, int HSTEP, int DVT, int WAVES>
+template <int NSTEP, int HSTEP, int DVT, int WAVES, bool PLAIN>
 __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void sam_attn_kernel(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp,
                                                          const _Float16* __restrict__ Vp, _Float16* __restrict__ out_pl,
                                                          AttnGeom a, unsigned* range_flag) {
-    using C = AttnCfg<NSTEP, HSTEP, DVT, WAVES>;
+    using C = AttnCfg<NSTEP, HSTEP, DVT, WAVES, PLAIN>;
     constexpr int NT = C::NT, QB = C::QB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Kh = reinterpret_cast<_Float16*>(smem);
@@ -249,20 +265,21 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void sam_attn_kernel(const _
     // Q'^T fragments (B operand of S^T = K'.Q'^T): lane (r, h) holds Q'[q = r][16 kg + 8 h + 0..7]; rows past Npad
     // read as zeros (buffer range check) — their waves only keep the barriers company
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<_Float16*>(Qp + (size_t)grp * a.Npad * 2 * C::DQ), 0, unsigned(a.Npad) * 2u * C::DQ * 2u, 0x00020000);
-    f16x8 qh[NSTEP], ql[NSTEP];
+        const_cast<_Float16*>(Qp + (size_t)grp * a.Npad * C::Q_ROW), 0, unsigned(a.Npad) * unsigned(C::Q_ROW) * 2u, 0x00020000);
+    f16x8 qh[NSTEP], ql[PLAIN ? 1 : NSTEP];
     {
-        const unsigned qoff = unsigned(q0 + wave * 32 + r) * unsigned(2 * C::DQ * 2) + unsigned(8 * h) * 2u;
+        const unsigned qoff = unsigned(q0 + wave * 32 + r) * unsigned(C::Q_ROW * 2) + unsigned(8 * h) * 2u;
 #pragma unroll
         for (int kg = 0; kg < NSTEP; ++kg) {
             qh[kg] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + kg * 32u, 0, 0));
-            ql[kg] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + C::DQ * 2u + kg * 32u, 0, 0));
+            if constexpr (!PLAIN)
+                ql[kg] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + C::DQ * 2u + kg * 32u, 0, 0));
         }
     }
 
     // K' / V tiles: 32 consecutive rows of the group are one contiguous blob; 16-byte pieces go to the padded LDS rows
-    const u32x4* kg_base = reinterpret_cast<const u32x4*>(Kp + (size_t)grp * a.Npad * (C::DQ + C::HDP));
-    const u32x4* vg_base = reinterpret_cast<const u32x4*>(Vp + (size_t)grp * a.Npad * 2 * C::DV);
+    const u32x4* kg_base = reinterpret_cast<const u32x4*>(Kp + (size_t)grp * a.Npad * C::K_ROW);
+    const u32x4* vg_base = reinterpret_cast<const u32x4*>(Vp + (size_t)grp * a.Npad * C::V_ROW);
     u32x4 rk[C::KP], rv[C::VP];
     auto load_kv = [&](int kt) {
 #pragma unroll
@@ -332,11 +349,13 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void sam_attn_kernel(const _
 #pragma unroll
         for (int kg = 0; kg < NSTEP; ++kg) {
             const f16x8 kh = *reinterpret_cast<const f16x8*>(kb_h + 16 * kg);
-            if (kg < HSTEP) {
-                const f16x8 kl = *reinterpret_cast<const f16x8*>(kb_l + 16 * kg);
-                s = mfma_f16(kl, qh[kg], s);
+            if constexpr (!PLAIN) {
+                if (kg < HSTEP) {
+                    const f16x8 kl = *reinterpret_cast<const f16x8*>(kb_l + 16 * kg);
+                    s = mfma_f16(kl, qh[kg], s);
+                }
+                s = mfma_f16(kh, ql[kg], s);
             }
-            s = mfma_f16(kh, ql[kg], s);
             s = mfma_f16(kh, qh[kg], s);
         }
         if (kt + 1 == nkt) {   // keys past the window (rows Nq..Npad of the planes are zeros)
@@ -378,16 +397,22 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void sam_attn_kernel(const _
                 p0[e] = s[8 * st + e];
                 p1[e] = s[8 * st + 4 + e];
             }
-            f16x4 h0, l0, h1, l1;
-            pope_split4(p0, h0, l0);
-            pope_split4(p1, h1, l1);
-            const f16x8 ph = cat(h0, h1), pl = cat(l0, l1);
+            if constexpr (PLAIN) {
+                const f16x8 ph = cat(__builtin_convertvector(p0, f16x4), __builtin_convertvector(p1, f16x4));
 #pragma unroll
-            for (int dt = 0; dt < DVT; ++dt) {
-                const f16x8 vh = vfrag(Vh, st, dt), vl = vfrag(Vl, st, dt);
-                o[dt] = mfma_f16(vl, ph, o[dt]);
-                o[dt] = mfma_f16(vh, pl, o[dt]);
-                o[dt] = mfma_f16(vh, ph, o[dt]);
+                for (int dt = 0; dt < DVT; ++dt) o[dt] = mfma_f16(vfrag(Vh, st, dt), ph, o[dt]);
+            } else {
+                f16x4 h0, l0, h1, l1;
+                pope_split4(p0, h0, l0);
+                pope_split4(p1, h1, l1);
+                const f16x8 ph = cat(h0, h1), pl = cat(l0, l1);
+#pragma unroll
+                for (int dt = 0; dt < DVT; ++dt) {
+                    const f16x8 vh = vfrag(Vh, st, dt), vl = vfrag(Vl, st, dt);
+                    o[dt] = mfma_f16(vl, ph, o[dt]);
+                    o[dt] = mfma_f16(vh, pl, o[dt]);
+                    o[dt] = mfma_f16(vh, ph, o[dt]);
+                }
             }
         }
     }
@@ -422,20 +447,78 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void sam_attn_kernel(const _
         if (n < a.Nq && y < a.g && x < a.g) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(&Os[lr * C::OST + c4]);
             pope_amax4x2(amax, v);
-            f16x4 hi, lo;
-            pope_split4(v * A_SCALE, hi, lo);
             const int col = head * C::HDP + c4;
-            _Float16* dst = out_pl + ((size_t)b * a.g * a.g + (size_t)y * a.g + x) * 2 * a.dim + (col >> 5) * 64 + (col & 31);
-            *reinterpret_cast<f16x4*>(dst) = hi;
-            *reinterpret_cast<f16x4*>(dst + 32) = lo;
+            const size_t trow = (size_t)b * a.g * a.g + (size_t)y * a.g + x;
+            if constexpr (PLAIN) {
+                *reinterpret_cast<f16x4*>(out_pl + trow * a.dim + col) = __builtin_convertvector(v * A_SCALE, f16x4);
+            } else {
+                f16x4 hi, lo;
+                pope_split4(v * A_SCALE, hi, lo);
+                _Float16* dst = out_pl + trow * 2 * a.dim + (col >> 5) * 64 + (col & 31);
+                *reinterpret_cast<f16x4*>(dst) = hi;
+                *reinterpret_cast<f16x4*>(dst + 32) = lo;
+            }
         }
     }
     pope_range_flag(range_flag, POPE_RANGE_QKV, !(fmaxf(amax[0], amax[1]) * A_SCALE < POPE_F16_OVERFLOW));
 }
 
+// ---- precision "f16": LayerNorm over the last dim -> f16 row-major (value * 8), one wave per row (dim % 128 == 0, <= 2048);
+// and the plain conversion fp32 -> f16 (value * 8) of the neck's input
+template <int NV>
+__global__ __launch_bounds__(256) void sam_ln_f16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, _Float16* __restrict__ y, int rows,
+                                                         float eps, unsigned* range_flag) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    constexpr int nv = NV, dim = NV * 128;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * dim;
+    f32x2 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < nv; ++i) {
+        v[i] = *reinterpret_cast<const f32x2*>(xr + i * 128 + lane * 2);
+        s += v[i][0] + v[i][1];
+    }
+    const float mean = wave_sum(s) / float(dim);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < nv; ++i) {
+        const float d0 = v[i][0] - mean, d1 = v[i][1] - mean;
+        q += d0 * d0 + d1 * d1;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / float(dim) + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < nv; ++i) {
+        const int c = i * 128 + lane * 2;
+        const f32x2 ww = *reinterpret_cast<const f32x2*>(w + c), bb = *reinterpret_cast<const f32x2*>(b + c);
+        f32x2 o;
+        o[0] = ((v[i][0] - mean) * rstd * ww[0] + bb[0]) * A_SCALE;
+        o[1] = ((v[i][1] - mean) * rstd * ww[1] + bb[1]) * A_SCALE;
+        amax = pope_amax2(amax, o);
+        *reinterpret_cast<f16x2*>(y + (size_t)row * dim + c) = __builtin_convertvector(o, f16x2);
+    }
+    pope_range_flag(range_flag, POPE_RANGE_LAYERNORM, !(amax < POPE_F16_OVERFLOW) || !(__builtin_fabsf(mean) + rstd < INFINITY));
+}
+
+__global__ __launch_bounds__(256) void sam_to_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, long long n4,
+                                                         unsigned* range_flag) {
+    float amax = 0.f;
+    for (long long id = blockIdx.x * 256ll + threadIdx.x; id < n4; id += 256ll * gridDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * id);
+        amax = pope_amax4(amax, v);
+        if (!((v[0] + v[1]) + (v[2] + v[3]) == (v[0] + v[1]) + (v[2] + v[3]))) amax = INFINITY;
+        *reinterpret_cast<f16x4*>(y + 4 * id) = __builtin_convertvector(v * A_SCALE, f16x4);
+    }
+    pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax * A_SCALE < POPE_F16_OVERFLOW));
+}
+
 // ---- neck LayerNorm2d (common.py:27-43: per pixel over the channels, eps inside the sqrt, a true division) -----------
 // in: fp32 [pixels, C] (C % 256 == 0, <= 1024); one wave per pixel, four channels per lane and 256-column group
-template <bool TO_BORDERED_PLANES>
+template <bool TO_BORDERED_PLANES, bool PLAIN = false>
 __global__ __launch_bounds__(256) void sam_ln2d_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                        const float* __restrict__ bvec, void* __restrict__ out, int B, int g, int C,
                                                        float eps, unsigned* range_flag) {
@@ -493,11 +576,15 @@ __global__ __launch_bounds__(256) void sam_ln2d_kernel(const float* __restrict__
             if (TO_BORDERED_PLANES) {
                 amax = pope_amax4(amax, r);
                 if (!((r[0] + r[1]) + (r[2] + r[3]) == (r[0] + r[1]) + (r[2] + r[3]))) amax = INFINITY;
-                f16x4 hi, lo;
-                pope_split4(r * A_SCALE, hi, lo);
-                _Float16* dst = static_cast<_Float16*>(out) + (size_t)pix * 2 * C + (col >> 5) * 64 + (col & 31);
-                *reinterpret_cast<f16x4*>(dst) = hi;
-                *reinterpret_cast<f16x4*>(dst + 32) = lo;
+                if constexpr (PLAIN) {
+                    *reinterpret_cast<f16x4*>(static_cast<_Float16*>(out) + (size_t)pix * C + col) = __builtin_convertvector(r * A_SCALE, f16x4);
+                } else {
+                    f16x4 hi, lo;
+                    pope_split4(r * A_SCALE, hi, lo);
+                    _Float16* dst = static_cast<_Float16*>(out) + (size_t)pix * 2 * C + (col >> 5) * 64 + (col & 31);
+                    *reinterpret_cast<f16x4*>(dst) = hi;
+                    *reinterpret_cast<f16x4*>(dst + 32) = lo;
+                }
             } else {
                 float* dst = static_cast<float*>(out) + (((size_t)b * C + col) * g + y) * g + x;
 #pragma unroll
@@ -535,13 +622,13 @@ bool plan_attention(int B, int g, int ws, int heads, int hd, AttnPlan& p) {
     return true;
 }
 
-template <int NSTEP, int HSTEP, int DVT, int WAVES>
+template <int NSTEP, int HSTEP, int DVT, int WAVES, bool PLAIN>
 int launch_attn(const AttnPlan& p, const _Float16* Qp, const _Float16* Kp, const _Float16* Vp, _Float16* out, unsigned* flag,
                 hipStream_t stream) {
-    using C = AttnCfg<NSTEP, HSTEP, DVT, WAVES>;
+    using C = AttnCfg<NSTEP, HSTEP, DVT, WAVES, PLAIN>;
     constexpr int NT = C::NT, QB = C::QB;
     static pope_dev_mask done{0};
-    auto kern = sam_attn_kernel<NSTEP, HSTEP, DVT, WAVES>;
+    auto kern = sam_attn_kernel<NSTEP, HSTEP, DVT, WAVES, PLAIN>;
     if (!pope_opt_in_lds(kern, C::LDS_BYTES, done)) return POPE_ERR_LAUNCH;
     const AttnGeom& a = p.geom;
     const long long blocks = (long long)a.B * a.nw * a.nw * a.heads * ((a.Nq + QB - 1) / QB);
@@ -618,6 +705,11 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
 
     const float eps = 1e-6f;   // build_sam.py:71; common.py:32
     unsigned* flag = q.range_flag;
+    // precision "f16" (POPE_PREC_F16): every operand is a plain f16 tensor (activations * 8, weights * 256), one MFMA per
+    // product, fp32 accumulation, fp32 residual stream / softmax / LayerNorm statistics — BASELINE config 5's dtype
+    if (q.precision != POPE_PREC_F16X3 && q.precision != POPE_PREC_F16) return POPE_ERR_ARG;
+    const bool plain = q.precision == POPE_PREC_F16;
+    if (plain && ((dim & 63) || (hidden & 63) || (kp & 63))) return POPE_ERR_ARG;
     int rc;
 #define POPE_TRY(call) do { if ((rc = (call))) return rc; } while (0)
     auto gemm = [&](const void* a_pl, const void* w_pl, const float* bias, float* Cf, void* c_pl, int N, int K, int epi,
@@ -626,16 +718,36 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
         gp_.range_flag = flag;
         gp_.range_bit = epi == EPI_BIAS_GELU ? POPE_RANGE_GELU : POPE_RANGE_QKV;
         gp_.a_pl = a_pl; gp_.w_pl = w_pl; gp_.bias = bias; gp_.C = Cf; gp_.c_pl = c_pl;
-        gp_.lda = K; gp_.ldw = K; gp_.ldc = N; gp_.M = rows; gp_.N = N; gp_.K = K;
+        const int Kc = plain ? K / 2 : K;   // plain: columns are counted in pairs (GemmParams::plain)
+        gp_.lda = Kc; gp_.ldw = Kc; gp_.ldc = plain && c_pl ? N / 2 : N; gp_.M = rows; gp_.N = N; gp_.K = Kc;
         gp_.epilogue = epi; gp_.gamma = gamma; gp_.res = res; gp_.ldres = N; gp_.res_mod = res_mod;
+        gp_.plain = plain;
         return pope_launch_gemm_nt_f16x3_planes(gp_, stream);
+    };
+    auto layernorm = [&](const float* w, const float* b) -> int {   // LN(x) -> xn_pl as this precision's GEMM operand
+        if (!plain) return pope_launch_layernorm_planes(x, dim, w, b, xn_pl, rows, dim, eps, flag, stream);
+#define POPE_SAM_LN(NV)                                                                                                  \
+    case NV:                                                                                                             \
+        hipLaunchKernelGGL(sam_ln_f16_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, b, static_cast<_Float16*>(xn_pl), \
+                           rows, eps, flag);                                                                             \
+        break;
+        switch (dim / 128) {
+            POPE_SAM_LN(2) POPE_SAM_LN(4) POPE_SAM_LN(5) POPE_SAM_LN(6) POPE_SAM_LN(8) POPE_SAM_LN(10) POPE_SAM_LN(12) POPE_SAM_LN(16)
+            default: return POPE_ERR_ARG;
+        }
+#undef POPE_SAM_LN
+        return pope_check_launch();
     };
 
     // patch embed + absolute position table (image_encoder.py:108-110): x = conv(img) + bias + pos[token]
     {
         const long long total = (long long)rows * (kp / 8);
-        hipLaunchKernelGGL(sam_im2col_kernel, dim3(grid_for(total)), dim3(256), 0, stream, q.image, reinterpret_cast<_Float16*>(big),
-                           q.B, q.img, q.patch, flag);
+        if (plain)
+            hipLaunchKernelGGL(sam_im2col_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, q.image,
+                               reinterpret_cast<_Float16*>(big), q.B, q.img, q.patch, flag);
+        else
+            hipLaunchKernelGGL(sam_im2col_kernel<false>, dim3(grid_for(total)), dim3(256), 0, stream, q.image,
+                               reinterpret_cast<_Float16*>(big), q.B, q.img, q.patch, flag);
         POPE_TRY(pope_check_launch());
         if (q.pos) POPE_TRY(gemm(big, q.patch_wp, q.patch_b, x, nullptr, dim, kp, EPI_BIAS_LS_RES, q.ones, q.pos, g * g));
         else POPE_TRY(gemm(big, q.patch_wp, q.patch_b, x, nullptr, dim, kp, EPI_BIAS, nullptr, nullptr, 0));
@@ -648,7 +760,7 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
         const AttnPlan& p = k.global || q.window <= 0 ? plan_g : plan_w;
         const AttnGeom& a = p.geom;
         // x = x + attn(norm1(x))                                         image_encoder.py:166-179
-        POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm1_w, k.norm1_b, xn_pl, rows, dim, eps, flag, stream));
+        POPE_TRY(layernorm(k.norm1_w, k.norm1_b));
         POPE_TRY(gemm(xn_pl, k.qkv_wp, k.qkv_b, qkv, nullptr, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, 0));
         _Float16* Qp = reinterpret_cast<_Float16*>(op_base);
         _Float16* Kp = reinterpret_cast<_Float16*>(op_base + align256(p.qp));
@@ -656,28 +768,34 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
         const int G = a.B * a.nw * a.nw * a.heads;
         {
             const long long total = (long long)G * a.Npad * (2 * (hd / 8) + (a.DQ - hd) / 8 + a.DV / 8);
-            hipLaunchKernelGGL(sam_attn_split_kernel, dim3(grid_for(total)), dim3(256), 0, stream, qkv, k.qkv_b, Qp, Kp, Vp, a, flag);
+            if (plain)
+                hipLaunchKernelGGL(sam_attn_split_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, qkv, k.qkv_b, Qp, Kp, Vp, a, flag);
+            else
+                hipLaunchKernelGGL(sam_attn_split_kernel<false>, dim3(grid_for(total)), dim3(256), 0, stream, qkv, k.qkv_b, Qp, Kp, Vp, a, flag);
             POPE_TRY(pope_check_launch());
             const int tpb = 256 / (a.DQ - hd);
             const dim3 rgrid((a.Npad + tpb - 1) / tpb, a.B * a.nw * a.nw);
             const size_t lds = size_t(tpb) * dim * sizeof(float);
-            if (hd == 80)
-                hipLaunchKernelGGL(sam_attn_relpos_kernel<80>, rgrid, dim3(256), lds, stream, qkv, k.qkv_b, k.rel_h, k.rel_w, Qp, a, flag);
-            else
-                hipLaunchKernelGGL(sam_attn_relpos_kernel<64>, rgrid, dim3(256), lds, stream, qkv, k.qkv_b, k.rel_h, k.rel_w, Qp, a, flag);
+#define POPE_SAM_RELPOS(HD, PL) \
+    hipLaunchKernelGGL((sam_attn_relpos_kernel<HD, PL>), rgrid, dim3(256), lds, stream, qkv, k.qkv_b, k.rel_h, k.rel_w, Qp, a, flag)
+            if (hd == 80) { if (plain) POPE_SAM_RELPOS(80, true); else POPE_SAM_RELPOS(80, false); }
+            else { if (plain) POPE_SAM_RELPOS(64, true); else POPE_SAM_RELPOS(64, false); }
+#undef POPE_SAM_RELPOS
             POPE_TRY(pope_check_launch());
         }
         _Float16* att = static_cast<_Float16*>(att_pl);
         static const int force_waves = getenv("POPE_SAM_ATTN_WAVES") ? atoi(getenv("POPE_SAM_ATTN_WAVES")) : 0;   // dev switch: 4 | 8
         const bool narrow = force_waves ? force_waves == 4 : a.Nq <= 1024;
-#define POPE_SAM_ATTN(NS, HS, DV)                                                                   \
-    (narrow ? launch_attn<NS, HS, DV, 4>(p, Qp, Kp, Vp, att, flag, stream) : launch_attn<NS, HS, DV, 8>(p, Qp, Kp, Vp, att, flag, stream))
+#define POPE_SAM_ATTN_W(NS, HS, DV, W) \
+    (plain ? launch_attn<NS, HS, DV, W, true>(p, Qp, Kp, Vp, att, flag, stream) : launch_attn<NS, HS, DV, W, false>(p, Qp, Kp, Vp, att, flag, stream))
+#define POPE_SAM_ATTN(NS, HS, DV) (narrow ? POPE_SAM_ATTN_W(NS, HS, DV, 4) : POPE_SAM_ATTN_W(NS, HS, DV, 8))
         if (hd == 80) POPE_TRY(p.nstep == 7 ? POPE_SAM_ATTN(7, 5, 3) : POPE_SAM_ATTN(13, 5, 3));
         else POPE_TRY(p.nstep == 6 ? POPE_SAM_ATTN(6, 4, 2) : POPE_SAM_ATTN(12, 4, 2));
 #undef POPE_SAM_ATTN
+#undef POPE_SAM_ATTN_W
         POPE_TRY(gemm(att_pl, k.proj_wp, k.proj_b, x, nullptr, dim, dim, EPI_BIAS_LS_RES, q.ones, x, 0));
         // x = x + mlp(norm2(x))                                          image_encoder.py:181; common.py:13-25
-        POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm2_w, k.norm2_b, xn_pl, rows, dim, eps, flag, stream));
+        POPE_TRY(layernorm(k.norm2_w, k.norm2_b));
         POPE_TRY(gemm(xn_pl, k.fc1_wp, k.fc1_b, nullptr, hid_pl, hidden, dim, EPI_BIAS_GELU, nullptr, nullptr, 0));
         POPE_TRY(gemm(hid_pl, k.fc2_wp, k.fc2_b, x, nullptr, dim, hidden, EPI_BIAS_LS_RES, q.ones, x, 0));
         for (int t = 0; t < q.n_taps; ++t)
@@ -686,26 +804,38 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
                 return POPE_ERR_LAUNCH;
     }
     // neck (image_encoder.py:89-105): 1x1 conv (no bias) -> LayerNorm2d -> 3x3 conv pad 1 (no bias) -> LayerNorm2d
-    POPE_TRY(pope_launch_split_planes(x, xn_pl, rows, dim, A_SCALE, flag, stream));
+    if (plain) {
+        const long long n4 = (long long)rows * dim / 4;
+        hipLaunchKernelGGL(sam_to_f16_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, x, static_cast<_Float16*>(xn_pl), n4, flag);
+        POPE_TRY(pope_check_launch());
+    } else {
+        POPE_TRY(pope_launch_split_planes(x, xn_pl, rows, dim, A_SCALE, flag, stream));
+    }
     POPE_TRY(gemm(xn_pl, q.neck0_wp, nullptr, t1, nullptr, oc, dim, EPI_BIAS, nullptr, nullptr, 0));
-    hipLaunchKernelGGL(sam_ln2d_kernel<true>, dim3(grid_for((long long)brows, 4)), dim3(256), 0, stream, t1, q.neck1_w, q.neck1_b, t1_pl,
-                       q.B, g, oc, eps, flag);
+    if (plain)
+        hipLaunchKernelGGL((sam_ln2d_kernel<true, true>), dim3(grid_for((long long)brows, 4)), dim3(256), 0, stream, t1, q.neck1_w,
+                           q.neck1_b, t1_pl, q.B, g, oc, eps, flag);
+    else
+        hipLaunchKernelGGL((sam_ln2d_kernel<true, false>), dim3(grid_for((long long)brows, 4)), dim3(256), 0, stream, t1, q.neck1_w,
+                           q.neck1_b, t1_pl, q.B, g, oc, eps, flag);
     POPE_TRY(pope_check_launch());
     {
         GemmParams c = {};
         const int Wp = g + 2;
         const size_t shift = size_t(Wp) + 1;   // output row R is pixel R + Wp + 1 (conv.hip)
         c.a_pl = t1_pl; c.w_pl = q.neck2_wp; c.bias = nullptr;
-        c.lda = oc; c.ldw = 9 * oc; c.ldc = oc;
-        c.M = int(brows - (2 * size_t(Wp) + 2)); c.N = oc; c.K = 9 * oc;
+        const int occ = plain ? oc / 2 : oc;   // plain: column pairs
+        c.lda = occ; c.ldw = 9 * occ; c.ldc = oc;
+        c.M = int(brows - (2 * size_t(Wp) + 2)); c.N = oc; c.K = 9 * occ;
+        c.plain = plain;
         c.epilogue = EPI_CONV; c.act_slope = 1.0f;   // identity
         c.C = t2 + shift * oc;
-        c.conv_cch = oc / 32; c.conv_wp = Wp;
+        c.conv_cch = occ / 32; c.conv_wp = Wp;
         c.range_flag = flag; c.range_bit = POPE_RANGE_INPUT;
         c.nbatch = 1;
         POPE_TRY(pope_launch_planes16(c, stream));
     }
-    hipLaunchKernelGGL(sam_ln2d_kernel<false>, dim3(grid_for((long long)rows, 4)), dim3(256), 0, stream, t2, q.neck3_w, q.neck3_b, q.out,
+    hipLaunchKernelGGL((sam_ln2d_kernel<false, false>), dim3(grid_for((long long)rows, 4)), dim3(256), 0, stream, t2, q.neck3_w, q.neck3_b, q.out,
                        q.B, g, oc, eps, nullptr);
     POPE_TRY(pope_check_launch());
 #undef POPE_TRY

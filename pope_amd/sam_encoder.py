@@ -125,27 +125,35 @@ class ImageEncoderViT(nn.Module):
         if eps != {1e-6}:
             raise NotImplementedError("pope_amd SAM encoder: LayerNorm eps is 1e-6 (build_sam.py:71; common.py:28): pass "
                                       "norm_layer=partial(torch.nn.LayerNorm, eps=1e-6)")
-        self.on_overflow = "raise"     # the encoder has no fp32-MFMA twin: leaving the f16x3 range is an error
+        # "f16x3" (default): fp32 operands as hi + lo f16, three MFMAs per product — fp32-level results (1e-5 from the
+        # reference).  "f16": BASELINE config 5's dtype — plain f16 operands, ONE MFMA per product, fp32 accumulation and an
+        # fp32 residual stream / softmax / LayerNorm; results at f16 level (a few 1e-3 from the fp32 reference).
+        self.precision = "f16x3"
+        self.on_overflow = "raise"     # the encoder has no fp32-MFMA twin: leaving the f16 range is an error
         self.overflow_events = 0
         self.max_batch = 8             # images per launch sequence (32-bit offsets of the GEMMs: 4096 x 5120 x 4 B x B)
-        self._wcache = None
+        self._wcache = {}
         self._ws = None
 
     # ---- host plumbing ---------------------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
-        self._wcache, self._ws = None, None
+        self._wcache, self._ws = {}, None
         return out
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
-        self._wcache = None
+        self._wcache = {}
         return out
 
     def _weights(self):
+        if self.precision not in ("f16x3", "f16"):
+            raise ValueError(f"ImageEncoderViT.precision must be 'f16x3' or 'f16', not {self.precision!r}")
+        plain = self.precision == "f16"
         dev_ptr = self.patch_embed.proj.weight.data_ptr()
-        if self._wcache is not None and self._wcache[0] == dev_ptr:
-            return self._wcache[1]
+        hit = self._wcache.get(self.precision)
+        if hit is not None and hit[0] == dev_ptr:
+            return hit[1]
         keep = []
 
         def P(t):
@@ -166,8 +174,11 @@ class ImageEncoderViT(nn.Module):
 
         def WP(t2d):
             k = t2d.shape[1]
-            assert k % 32 == 0
-            pl = _lib.to_planes(t2d.detach().float(), _lib.PLANES_W_SCALE)
+            assert k % (64 if plain else 32) == 0
+            if plain:   # f16 row-major, value * 256
+                pl = (t2d.detach().float() * _lib.PLANES_W_SCALE).half().contiguous()
+            else:
+                pl = _lib.to_planes(t2d.detach().float(), _lib.PLANES_W_SCALE)
             keep.append(pl)
             return C.c_void_p(pl.data_ptr())
 
@@ -196,6 +207,7 @@ class ImageEncoderViT(nn.Module):
         s = _lib.SamEncoderWeights()
         s.img, s.patch, s.dim, s.depth, s.heads = self.img_size, self.patch_size, dim, self.depth, self.num_heads
         s.hidden, s.out_chans, s.window = self.blocks[0].mlp.lin1.out_features, self.out_chans, self.window_size
+        s.precision = _lib.PREC_F16 if plain else _lib.PREC_F16X3
         s.patch_wp, s.patch_b = WP(self.patch_embed.proj.weight.reshape(dim, -1)), P(self.patch_embed.proj.bias)
         s.pos = P(self.pos_embed.reshape(grid * grid, dim)) if self.pos_embed is not None else None
         s.ones = P(torch.ones(dim, device=dev))
@@ -205,7 +217,7 @@ class ImageEncoderViT(nn.Module):
         s.neck2_wp = WP(self.neck[2].weight.permute(0, 2, 3, 1).reshape(self.out_chans, -1))   # taps (ky, kx, channel)
         s.neck3_w, s.neck3_b = P(self.neck[3].weight), P(self.neck[3].bias)
         keep.append(blocks)
-        self._wcache = (dev_ptr, s, keep)
+        self._wcache[self.precision] = (dev_ptr, s, keep)
         return s
 
     def _workspace(self, w, b, device):

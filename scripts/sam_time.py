@@ -1,4 +1,4 @@
-"""Time the SAM image encoder (BASELINE config 5) on one GPU: `python scripts/sam_time.py [arch] [batch] [iters]`
+"""Time the SAM image encoder (BASELINE config 5) on one GPU: `python scripts/sam_time.py [arch] [batch] [iters] [f16x3|f16]`
 (arch: vit_h | vit_l | vit_b).  Prints ms / image and algorithmic TFLOP/s (2 x MACs of the reference's own ops)."""
 import sys
 from functools import partial
@@ -31,12 +31,14 @@ def main():
     arch = sys.argv[1] if len(sys.argv) > 1 else "vit_h"
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    precision = sys.argv[4] if len(sys.argv) > 4 else "f16x3"
     dim, depth, heads, gidx = ARCHS[arch]
     m = ImageEncoderViT(depth=depth, embed_dim=dim, img_size=1024, mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
                         num_heads=heads, patch_size=16, qkv_bias=True, use_rel_pos=True, global_attn_indexes=list(gidx),
                         window_size=14, out_chans=256)
     m.load_state_dict(synth.synthetic_sam_encoder_state_dict(seed=0, dim=dim, depth=depth, heads=heads, global_idx=gidx), strict=True)
     m = m.eval().cuda()
+    m.precision = precision
     x = synth.synthetic_images(batch, 1024, 1024, seed=1).cuda()
     m(x)
     torch.cuda.synchronize()
@@ -48,7 +50,7 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     f = flops(dim, depth, heads, gidx)
-    print(f"{arch} batch {batch}: {ms / batch:.2f} ms / image, {batch * 1e3 / ms:.1f} images/s, "
+    print(f"{arch} [{precision}] batch {batch}: {ms / batch:.2f} ms / image, {batch * 1e3 / ms:.1f} images/s, "
           f"{f * batch / ms / 1e9:.1f} TFLOP/s algorithmic ({f / 1e12:.2f} TF / image), finite={bool(torch.isfinite(out).all())}")
 
 
