@@ -445,7 +445,7 @@ def config5_leg(device, iters=3):
         ok = bool(torch.isfinite(y).all()) and torch.equal(fn(x[:1])[0], y[0])
         return e0.elapsed_time(e1) / iters, ok
 
-    out = {"note": "synthetic weights and inputs; f16x3 arithmetic; images resident in HBM", "iters": iters}
+    out = {"note": "synthetic weights and inputs; images resident in HBM; f16x3 arithmetic unless an entry says dtype f16", "iters": iters}
     try:
         m = dinov2.vit_large(patch_size=14, img_size=518, init_values=1e-5, ffn_layer="mlp", block_chunks=0)
         m.load_state_dict(synth.synthetic_state_dict(seed=0, dim=1024, depth=24), strict=True)
@@ -468,13 +468,21 @@ def config5_leg(device, iters=3):
         enc.load_state_dict(synth.synthetic_sam_encoder_state_dict(seed=0, global_idx=gidx), strict=True)
         enc = enc.eval().to(device)
         x = synth.synthetic_images(4, 1024, 1024, seed=3, device=device)
-        ms, ok = timed(enc, x)
         n, dim, hd, heads = 4096, 1280, 80, 16
         lin = n * (768 * dim + 32 * 12 * dim * dim + dim * 256 + 9 * 256 * 256)
         att = 4 * heads * (n * n * 2 * hd + n * 128 * hd) + 28 * 25 * heads * (196 * 196 * 2 * hd + 196 * 28 * hd)
         fl = 2.0 * (lin + att)
-        out["sam_vit_h_encoder"] = {"value": round(4e3 / ms, 1), "unit": "images/s", "batch": 4, "image": [1024, 1024],
-                                    "ms_per_image": round(ms / 4, 3), "tflops_algorithmic": round(fl * 4 / ms / 1e9, 1), "verified": ok}
+        ref_out = None
+        for prec, key in (("f16x3", "sam_vit_h_encoder"), ("f16", "sam_vit_h_encoder_f16")):
+            enc.precision = prec   # f16x3: fp32-level results; f16: config 5's dtype, one MFMA per product
+            ms, ok = timed(enc, x)
+            out[key] = {"value": round(4e3 / ms, 1), "unit": "images/s", "batch": 4, "image": [1024, 1024], "dtype": prec,
+                        "ms_per_image": round(ms / 4, 3), "tflops_algorithmic": round(fl * 4 / ms / 1e9, 1), "verified": ok}
+            y = enc(x[:1])
+            if ref_out is None:
+                ref_out = y
+            else:   # the f16 mode against the f16x3 result of the same weights and image
+                out[key]["max_abs_diff_vs_f16x3"] = round(float((y - ref_out).abs().max()), 5)
         del enc, x
         torch.cuda.empty_cache()
     except Exception as e:  # noqa: BLE001
