@@ -13,7 +13,11 @@
 // (image_encoder.py:251-254, padded AFTER norm1) get k = v = the qkv bias, exactly what Linear(0) gives the reference.
 // `sam_attn_kernel` is the single-stage f16x3 flash kernel of attention_f16x3.hip re-cut for 32-key tiles, a
 // K depth of 16 * NSTEP and 32 * DVT value columns; its epilogue un-partitions (drops the pad queries) and writes the
-// activation planes of the proj GEMM.
+// activation planes of the proj GEMM.  (Two LDS stages with one barrier per tile were measured and dropped: global
+// blocks 0.83 -> 0.87 ms, window blocks 0.082 -> 0.080 ms in the f16 mode; the tile is bound by its own MFMA + softmax
+// chain at two waves per SIMD, not by the staging.)
+// Two precisions (pope_hip.h): POPE_PREC_F16X3 as above; POPE_PREC_F16 = plain f16 operands, one MFMA per product
+// (template flag PLAIN here and in gemm_planes.hip), fp32 accumulators / softmax / LayerNorm / residual stream in both.
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
@@ -198,15 +202,14 @@ __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __res
     if (n < a.Npad) {
         for (int head = 0; head < a.heads; ++head) {
             const float* q = &sq[(t * a.heads + head) * HD];
-            float acc = 0.f;
+            f32x2 acc2[2] = {{0.f, 0.f}, {0.f, 0.f}};   // four partial sums, two v_pk_fma_f32 per 16-byte LDS broadcast
 #pragma unroll
             for (int c = 0; c < HD / 4; ++c) {
                 const f32x4 q4 = *reinterpret_cast<const f32x4*>(q + 4 * c);
-                acc = fmaf(q4[0], R[c][0], acc);
-                acc = fmaf(q4[1], R[c][1], acc);
-                acc = fmaf(q4[2], R[c][2], acc);
-                acc = fmaf(q4[3], R[c][3], acc);
+                acc2[0] = __builtin_elementwise_fma(f32x2{q4[0], q4[1]}, f32x2{R[c][0], R[c][1]}, acc2[0]);
+                acc2[1] = __builtin_elementwise_fma(f32x2{q4[2], q4[3]}, f32x2{R[c][2], R[c][3]}, acc2[1]);
             }
+            float acc = (acc2[0][0] + acc2[0][1]) + (acc2[1][0] + acc2[1][1]);
             acc *= L2E;
             amax = fmaxf(amax, fabsf(acc));
             if (!(acc == acc)) amax = INFINITY;
