@@ -451,11 +451,20 @@ def config5_leg(device, iters=3):
         m.load_state_dict(synth.synthetic_state_dict(seed=0, dim=1024, depth=24), strict=True)
         m = m.eval().to(device)
         x = synth.synthetic_images(16, H_IMG, W_IMG, seed=3, device=device)
-        ms, ok = timed(lambda t: m(t, is_training=True)["x_norm_patchtokens"], x)
         npt = NTOK - 1
         fl = 2.0 * (1024 * 3 * 196 * npt + 24 * (NTOK * 12 * 1024 * 1024 + 2 * NTOK * NTOK * 1024))
-        out["dinov2_vit_l14"] = {"value": round(16e3 / ms, 1), "unit": "images/s", "batch": 16, "image": [H_IMG, W_IMG],
-                                 "ms_per_image": round(ms / 16, 3), "tflops_algorithmic": round(fl * 16 / ms / 1e9, 1), "verified": ok}
+        ref_out = None
+        for prec, key in (("f16x3", "dinov2_vit_l14"), ("f16", "dinov2_vit_l14_f16")):
+            m.precision = prec
+            ms, ok = timed(lambda t: m(t, is_training=True)["x_norm_patchtokens"], x)
+            out[key] = {"value": round(16e3 / ms, 1), "unit": "images/s", "batch": 16, "image": [H_IMG, W_IMG], "dtype": prec,
+                        "ms_per_image": round(ms / 16, 3), "tflops_algorithmic": round(fl * 16 / ms / 1e9, 1),
+                        "verified": ok and m.overflow_events == 0}
+            y = m(x[:1], is_training=True)["x_norm_patchtokens"]
+            if ref_out is None:
+                ref_out = y
+            else:
+                out[key]["max_abs_diff_vs_f16x3"] = round(float((y - ref_out).abs().max()), 5)
         del m, x
         torch.cuda.empty_cache()
     except Exception as e:  # noqa: BLE001 — reported, not hidden

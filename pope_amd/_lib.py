@@ -53,7 +53,7 @@ class SamEncoderWeights(C.Structure):
 # name -> (restype, argtypes); every symbol declared in include/pope_hip.h
 PREC_F32_MFMA, PREC_F16X3, PREC_F16 = 0, 1, 2
 PLANES_ACT_SCALE, PLANES_W_SCALE = 8.0, 256.0
-PRECISIONS = {"f32": PREC_F32_MFMA, "f16x3": PREC_F16X3}
+PRECISIONS = {"f32": PREC_F32_MFMA, "f16x3": PREC_F16X3, "f16": PREC_F16}
 c_uint_p = C.POINTER(C.c_uint)
 F16_MAX = 65504.0
 # bits of an f16x3 range-guard word (pope_hip.h POPE_RANGE_*)

@@ -237,7 +237,7 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
     if (n_taps < 0 || (n_taps > 0 && (!tap_blocks_host || !tap_out_host))) return POPE_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int dim = w->dim, hidden = w->hidden, prec = w->precision;
-    if (prec != POPE_PREC_F32_MFMA && prec != POPE_PREC_F16X3) return POPE_ERR_ARG;
+    if (prec != POPE_PREC_F32_MFMA && prec != POPE_PREC_F16X3 && prec != POPE_PREC_F16) return POPE_ERR_ARG;
     const int ntok = 1 + (H / w->patch) * (W / w->patch);
     const int rows = B * ntok;
     if (workspace_bytes < pope_vit_workspace_bytes(B, ntok, dim, hidden)) return POPE_ERR_WORKSPACE;
@@ -255,11 +255,16 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
     // f16x3 = the planes dataflow end to end (every operand is split ONCE by its producer, which also guards the f16
     // range: range_flag).  It needs the weight planes of all four Linear layers of every block; without them (or with
     // a width the planes layout does not take) the model runs on the fp32 MFMA, which has no range contract.
-    bool planes = prec == POPE_PREC_F16X3 && dim % 32 == 0 && dim >= 64 && hidden % 32 == 0;
+    bool planes = (prec == POPE_PREC_F16X3 || prec == POPE_PREC_F16) && dim % 32 == 0 && dim >= 64 && hidden % 32 == 0;
     for (int i = 0; planes && i < w->depth; ++i) {
         const pope_vit_block_weights& k = w->blocks_host[i];
         planes = k.qkv_wp && k.proj_wp && k.fc1_wp && k.fc2_wp;
     }
+    // POPE_PREC_F16: the blocks' Linear layers and attention in plain f16 (one MFMA per product; `*_wp` of the blocks
+    // are f16 row-major matrices, value * 256); the patch embed stays f16x3 (`patch_wp` = planes) and the residual
+    // stream, LayerNorm statistics, softmax and GELU fp32.  Needs the weights and widths the plain GEMM takes.
+    const bool plain = prec == POPE_PREC_F16;
+    if (plain && (!planes || !w->patch_wp || (dim & 63) || (hidden & 63))) return POPE_ERR_ARG;
     const int f32 = POPE_PREC_F32_MFMA;
 
 #define POPE_MARK(kind) do { if (!rec.mark(kind, stream)) return POPE_ERR_ARG; } while (0)
@@ -273,7 +278,19 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
     static const bool no_rowln = getenv("POPE_NO_ROWLN") && atoi(getenv("POPE_NO_ROWLN"));
     GemmParams probe = {};
     probe.M = rows; probe.N = dim; probe.K = dim; probe.lda = dim; probe.ldw = dim; probe.ldc = dim; probe.ldres = dim;
-    const bool fused = planes && w->patch_wp && !no_rowln && pope_gemm_rowln_supported(probe);
+    const bool fused = planes && !plain && w->patch_wp && !no_rowln && pope_gemm_rowln_supported(probe);
+    // plain GEMM over the token rows: C (fp32) or c_f16 (f16 row-major) = epi(a_f16 . w_f16^T + bias [...])
+    auto plain_gemm = [&](const void* a_f16, const void* w_f16, const float* bias, float* Cf, void* c_f16, int N, int K, int epi,
+                          const float* gamma, const float* res) {
+        GemmParams g = {};
+        g.range_flag = range_flag;
+        g.range_bit = epi == EPI_BIAS_GELU ? POPE_RANGE_GELU : POPE_RANGE_QKV;
+        g.a_pl = a_f16; g.w_pl = w_f16; g.bias = bias; g.C = Cf; g.c_pl = c_f16;
+        g.lda = K / 2; g.ldw = K / 2; g.K = K / 2; g.ldc = c_f16 ? N / 2 : N;   // column pairs (GemmParams::plain)
+        g.M = rows; g.N = N; g.epilogue = epi; g.gamma = gamma; g.res = res; g.ldres = N;
+        g.plain = 1;
+        return pope_launch_gemm_nt_f16x3_planes(g, stream);
+    };
     // residual GEMM + following LayerNorm: x = res + gamma * (a . W^T + bias); LN(x; ln_w, ln_b) -> planes or fp32
     auto rowln = [&](const void* a_pl, const void* w_pl, int K, const float* bias, const float* gamma, const float* res, int res_mod,
                      const float* ln_w, const float* ln_b, void* ln_planes, float* ln_f32) {
@@ -302,6 +319,29 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
         const pope_vit_block_weights& k = w->blocks_host[i];
         const bool last = i + 1 == w->depth;
         // x = x + ls1(attn(norm1(x)))                                      block.py:105
+        if (plain) {   // the same seven launches per block in single-product f16 arithmetic
+            POPE_MARK(POPE_K_LAYERNORM);
+            POPE_TRY(pope_launch_layernorm_f16(x, k.norm1_w, k.norm1_b, xn_pl, rows, dim, eps, range_flag, stream));
+            POPE_MARK(POPE_K_GEMM_QKV);
+            POPE_TRY(plain_gemm(xn_pl, k.qkv_wp, k.qkv_b, qkv, nullptr, 3 * dim, dim, EPI_BIAS, nullptr, nullptr));
+            POPE_MARK(POPE_K_ATTENTION);
+            POPE_TRY(pope_launch_attention_f16_plain(qkv, att, B, ntok, w->heads, stream));
+            POPE_MARK(POPE_K_GEMM_PROJ);
+            POPE_TRY(plain_gemm(att, k.proj_wp, k.proj_b, x, nullptr, dim, dim, EPI_BIAS_LS_RES, k.ls1, x));
+            POPE_MARK(POPE_K_LAYERNORM);
+            POPE_TRY(pope_launch_layernorm_f16(x, k.norm2_w, k.norm2_b, xn_pl, rows, dim, eps, range_flag, stream));
+            POPE_MARK(POPE_K_GEMM_FC1);
+            POPE_TRY(plain_gemm(xn_pl, k.fc1_wp, k.fc1_b, nullptr, hid_pl, hidden, dim, EPI_BIAS_GELU, nullptr, nullptr));
+            POPE_MARK(POPE_K_GEMM_FC2);
+            POPE_TRY(plain_gemm(hid_pl, k.fc2_wp, k.fc2_b, x, nullptr, dim, hidden, EPI_BIAS_LS_RES, k.ls2, x));
+            for (int t = 0; t < n_taps; ++t)
+                if (tap_blocks_host[t] == i && tap_out_host[t]) {
+                    POPE_MARK(POPE_K_TAP_COPY);
+                    if (hipMemcpyAsync(tap_out_host[t], x, size_t(rows) * dim * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                        return POPE_ERR_LAUNCH;
+                }
+            continue;
+        }
         if (!fused) {
             POPE_MARK(POPE_K_LAYERNORM);
             if (planes) POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm1_w, k.norm1_b, xn_pl, rows, dim, eps, range_flag, stream));

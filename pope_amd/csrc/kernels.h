@@ -115,6 +115,11 @@ int pope_launch_gemm_nt_f16x3(const GemmParams& g, hipStream_t stream);
 int pope_launch_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
                               int rows, int dim, float eps, hipStream_t stream);
 
+// POPE_PREC_F16 pieces of the DINOv2 path (sam.hip, attention_f16x3.hip): LayerNorm -> f16 row-major (value * 8); attention with
+// fp32 qkv in, plain f16 arithmetic, f16 row-major output (value * 8)
+int pope_launch_layernorm_f16(const float* x, const float* w, const float* b, void* y_f16, int rows, int dim, float eps, unsigned* flag,
+                              hipStream_t stream);
+int pope_launch_attention_f16_plain(const float* qkv, void* out_f16, int B, int N, int heads, hipStream_t stream);
 // Multi-head softmax attention over qkv[B, N, 3, heads, 64] -> out[B, N, heads*64].
 int pope_launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream);
 int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream);

@@ -642,6 +642,23 @@ int launch_attn(const AttnPlan& p, const _Float16* Qp, const _Float16* Kp, const
 
 }  // namespace
 
+// y = LayerNorm(x) * w + b as f16 row-major (value * 8): the A operand of the plain-f16 GEMMs (POPE_PREC_F16)
+int pope_launch_layernorm_f16(const float* x, const float* w, const float* b, void* y_f16, int rows, int dim, float eps, unsigned* flag,
+                              hipStream_t stream) {
+    if (!x || !w || !b || !y_f16 || rows <= 0) return POPE_ERR_ARG;
+#define POPE_SAM_LN(NV)                                                                                                       \
+    case NV:                                                                                                                  \
+        hipLaunchKernelGGL(sam_ln_f16_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, b, static_cast<_Float16*>(y_f16), \
+                           rows, eps, flag);                                                                                  \
+        break;
+    switch (dim % 128 ? 0 : dim / 128) {
+        POPE_SAM_LN(2) POPE_SAM_LN(3) POPE_SAM_LN(4) POPE_SAM_LN(5) POPE_SAM_LN(6) POPE_SAM_LN(8) POPE_SAM_LN(10) POPE_SAM_LN(12) POPE_SAM_LN(16)
+        default: return POPE_ERR_ARG;
+    }
+#undef POPE_SAM_LN
+    return pope_check_launch();
+}
+
 size_t pope_sam_encoder_workspace(const SamEncParams& q) {
     if (q.B <= 0 || q.img <= 0 || q.patch <= 0 || q.img % q.patch || q.heads <= 0 || q.dim % q.heads) return 0;
     const int g = q.img / q.patch, hd = q.dim / q.heads;
@@ -729,17 +746,7 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
     };
     auto layernorm = [&](const float* w, const float* b) -> int {   // LN(x) -> xn_pl as this precision's GEMM operand
         if (!plain) return pope_launch_layernorm_planes(x, dim, w, b, xn_pl, rows, dim, eps, flag, stream);
-#define POPE_SAM_LN(NV)                                                                                                  \
-    case NV:                                                                                                             \
-        hipLaunchKernelGGL(sam_ln_f16_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, b, static_cast<_Float16*>(xn_pl), \
-                           rows, eps, flag);                                                                             \
-        break;
-        switch (dim / 128) {
-            POPE_SAM_LN(2) POPE_SAM_LN(4) POPE_SAM_LN(5) POPE_SAM_LN(6) POPE_SAM_LN(8) POPE_SAM_LN(10) POPE_SAM_LN(12) POPE_SAM_LN(16)
-            default: return POPE_ERR_ARG;
-        }
-#undef POPE_SAM_LN
-        return pope_check_launch();
+        return pope_launch_layernorm_f16(x, w, b, xn_pl, rows, dim, eps, flag, stream);
     };
 
     // patch embed + absolute position table (image_encoder.py:108-110): x = conv(img) + bias + pos[token]

@@ -127,6 +127,42 @@ def test_vote_top3_matches_reference_loop(model, sd0):
     assert list(idx) == list(want_idx) and 4 in idx
 
 
+@pytest.mark.parametrize("name", ["vit_224", "vit_476x630", "vitb_224", "vitl_224"])
+def test_f16_precision_mode(hip_lib, golden_dir, sd0, name):
+    """precision = "f16" (opt-in; BASELINE config 5's dtype): plain f16 operands, one MFMA per product in every block's
+    Linear layers and attention, fp32 accumulation / residual stream / softmax / LayerNorm.  Against the fp32 reference
+    fixtures the descriptors carry f16 rounding through the depth of the model: held to 1e-2 abs and 1e-3 mean (measured
+    1.8e-3 ... 3.2e-3 and 2.7e-4 ... 4.6e-4)."""
+    from pope_amd import dinov2, synth
+    from pope_amd.dinov2_utils import load_dinov2_model
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    if "arch" in fx:
+        dim, depth, heads = (int(v) for v in fx["arch"])
+        m = (dinov2.vit_base if dim == 768 else dinov2.vit_large)(patch_size=14, img_size=518, init_values=1e-5, ffn_layer="mlp",
+                                                                  block_chunks=0)
+        m.load_state_dict(synth.synthetic_state_dict(seed=int(fx["weights_seed"]), dim=dim, depth=depth), strict=True)
+        m = m.eval().to("cuda:0")
+    else:
+        m = load_dinov2_model(state_dict=sd0).to("cuda:0")
+    m.precision = "f16"
+    B, H, W = (int(v) for v in fx["shape"])
+    x = synth.synthetic_images(B, H, W, seed=int(fx["input_seed"])).cuda()
+    out = m(x, is_training=True)
+    rows = torch.from_numpy(fx["rows"])
+    xn = torch.cat([out["x_norm_clstoken"][:, None], out["x_norm_patchtokens"]], 1).cpu()[:, rows].numpy()
+    err = np.abs(xn - fx["x_norm"])
+    print(f"{name} [f16]: max |x_norm - reference| = {err.max():.2e}, mean {err.mean():.2e}")
+    assert np.isfinite(xn).all() and err.max() <= 1e-2 and err.mean() <= 1e-3
+    assert m.overflow_events == 0
+    assert torch.equal(m(x, is_training=True)["x_norm_patchtokens"], out["x_norm_patchtokens"])   # deterministic
+    x3 = torch.cat([synth.synthetic_images(2, H, W, seed=3).cuda(), x[:1]])                        # batch invariant
+    assert torch.equal(m(x3, is_training=True)["x_norm_patchtokens"][2], out["x_norm_patchtokens"][0])
+    m.precision = "f16x3"   # the modes keep separate weight caches
+    xn3 = torch.cat([m(x, is_training=True)[k][:, None] if k.endswith("clstoken") else m(x, is_training=True)[k]
+                     for k in ("x_norm_clstoken", "x_norm_patchtokens")], 1).cpu()[:, rows].numpy()
+    np.testing.assert_allclose(xn3, fx["x_norm"], rtol=0, atol=ATOL)
+
+
 @pytest.mark.parametrize("prec", ["f16x3", "f32"])
 @pytest.mark.parametrize("name", ["vitb_224", "vitl_224"])
 def test_vit_base_and_large_match_reference_fixture(hip_lib, golden_dir, name, prec):
