@@ -145,7 +145,9 @@ typedef struct pope_vit_weights {
     const float* patch_w;                 /* patch_embed.proj.weight flattened [dim, 3*patch^2] */
     const float *norm_w, *norm_b;         /* final norm                                         */
     const pope_vit_block_weights* blocks_host; /* HOST array [depth] of device-pointer structs  */
-    int precision;                        /* POPE_PREC_* of the Linear layers and of attention  */
+    int precision;                        /* POPE_PREC_* of the Linear layers and of attention; POPE_PREC_F16 (opt-in): the
+                                             blocks' `*_wp` are plain f16 row-major matrices (value * 256), one MFMA per
+                                             product; patch_wp stays weight planes (the patch embed is f16x3) */
     const void* patch_wp;                 /* optional: patch_w as weight planes [dim, kp], kp = 3*patch^2 rounded up to a
                                              multiple of 32 with zero columns; enables the f16x3 patch embed */
 } pope_vit_weights;
