@@ -42,7 +42,11 @@ PEAK_HBM_GBS = 8000.0
 # executed per algorithmic FLOP (f16x3 = three partial products per product block)
 PRECISION_INFO = {"f16x3": ("f16x3 (fp32 operands split hi+lo into f16, 3 MFMAs per product, fp32 accumulate)",
                             PEAK_F16_MFMA_TFLOPS, 3),
-                  "f32": ("f32 (v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS, 1)}
+                  "f32": ("f32 (v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS, 1),
+                  # opt-in reduced precision (never the default line: the reference path is fp32): the ViT blocks in plain f16,
+                  # one MFMA per product; patch embed and the matcher contraction stay f16x3
+                  "f16": ("f16 (ViT blocks: plain f16 operands, 1 MFMA per product, fp32 accumulate; patch embed + matcher f16x3)",
+                          PEAK_F16_MFMA_TFLOPS, 1)}
 PAIR_LIST = os.path.join(ROOT, "tests", "golden", "linemod_pairs.json")
 
 
@@ -196,10 +200,11 @@ def main():
     from pope_amd.pipeline import PairPipeline, gather_counts, load_pair_list, shard_range, walk_pair_list
 
     model = load_dinov2_model(state_dict=synth.synthetic_state_dict(seed=0)).to(device)
+    match_precision = "f16x3" if args.precision == "f16" else args.precision
     model.precision = args.precision
-    model._bench_match_precision = args.precision
+    model._bench_match_precision = match_precision
     dtype_name, peak_tflops, mfma_factor = PRECISION_INFO[args.precision]
-    pipe = PairPipeline(model, chunk=args.chunk, streams=args.streams, match_precision=args.precision)
+    pipe = PairPipeline(model, chunk=args.chunk, streams=args.streams, match_precision=match_precision)
     from pope_amd.profiling import KernelProfiler
 
     def fence():
@@ -327,7 +332,7 @@ def main():
         fl = kernel_flops(dominant, args.chunk)
         dom = {"kernel": dominant, "launches": v["launches"], "avg_ms": round(v["avg_ms"], 4),
                "tflops": round(fl / v["avg_ms"] / 1e9, 2)}
-        result["roofline"] = roofline_entry(dominant, dom, peak_tflops, mfma_factor, args.chunk)
+        result["roofline"] = roofline_entry(dominant, dom, peak_tflops, mfma_factor, args.chunk, pmc=args.precision != "f16")
         if tab:
             result["kernels"] = tab
             result["kernels_note"] = "every launch of the last warm-up step bracketed by HIP events"
@@ -404,10 +409,10 @@ def from_host_leg(pipe, args, device, steps=4):
                     "normalise -> the same extract + match step; PCIe-inclusive, not the headline"}
 
 
-def roofline_entry(dominant, dom, peak_tflops, mfma_factor, chunk):
+def roofline_entry(dominant, dom, peak_tflops, mfma_factor, chunk, pmc=True):
     traffic = None  # PMC-derived bytes per launch, collected in separate rocprofv3 --pmc passes (profiles/)
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(dominant)
+    try:            # (measured on the default f16x3 kernels: pmc=False for a mode whose kernels were not profiled that way)
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(dominant) if pmc else None
     except (OSError, ValueError):
         pass
     return {
@@ -530,7 +535,8 @@ def strict_f32_leg(model, pipe, img0, img1, args, steps=2):
                 "roofline": roofline_entry("attention", dom, peak, factor, args.chunk)}
     finally:
         model.profiler = None
-        model.precision = pipe.match_precision = args.precision
+        model.precision = args.precision
+        pipe.match_precision = "f16x3" if args.precision == "f16" else args.precision
 
 
 if __name__ == "__main__":
