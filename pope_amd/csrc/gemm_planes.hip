@@ -331,6 +331,26 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
             bias = bias * gamma;
             gamma = gamma * inv;
         }
+        // EPI_SAM_QKV: this wave's 64 columns lie in ONE of q / k / v (dim % 64 == 0); a lane's four columns in one head
+        [[maybe_unused]] int sq_head = 0, sq_c = 0, sq_row_h = 0, sq_lo = 0;
+        [[maybe_unused]] float sq_scale = 1.0f;
+        [[maybe_unused]] __amdgpu_buffer_rsrc_t rsq = rres, rmap = rres;
+        if constexpr (EPI == EPI_SAM_QKV) {
+            const int wcol = n0 + wn * 64;
+            const int which = __builtin_amdgcn_readfirstlane((wcol < g.N ? wcol : 0) / g.sam_dim);
+            const int rem = colc - which * g.sam_dim;
+            sq_head = rem / g.sam_hd;
+            sq_c = rem - sq_head * g.sam_hd;
+            // rows: Q' [DQ hi | DQ lo], K' [DQ hi | hd lo], V [DV hi | DV lo]; PLAIN: the hi parts only
+            sq_row_h = which == 0 ? (PLAIN ? g.sam_dq : 2 * g.sam_dq) : which == 1 ? (PLAIN ? g.sam_dq : g.sam_dq + g.sam_hd)
+                                                                                   : (PLAIN ? g.sam_dv : 2 * g.sam_dv);
+            sq_lo = which == 2 ? g.sam_dv : g.sam_dq;
+            sq_scale = which == 0 ? g.sam_qscale : 1.0f;
+            void* dst = which == 0 ? g.sam_q : which == 1 ? g.sam_k : g.sam_v;
+            const unsigned bytes = which == 0 ? g.sam_bytes[0] : which == 1 ? g.sam_bytes[1] : g.sam_bytes[2];
+            rsq = __builtin_amdgcn_make_buffer_rsrc(dst, 0, bytes, 0x00020000);
+            rmap = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(g.sam_rowmap), 0, unsigned(g.M) * 4u, 0x00020000);
+        }
         __syncthreads();  // all waves have finished reading the last K-step stage
         float* E = epi + wave * 32 * EPI_ST;
         f32x2 amax = {0.f, 0.f};  // OUT_PLANES: largest magnitude written as planes (range guard; rows >= M hold finite
@@ -345,6 +365,12 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
                 for (int i = 0; i < 8; ++i)
                     res[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                  rres, col_ok ? res_row(row0 + 4 * i) * unsigned(g.ldres) * 4u + unsigned(col) * 4u : DROP, 0, 0));
+            }
+            [[maybe_unused]] unsigned sq_dest[8];
+            if constexpr (EPI == EPI_SAM_QKV) {   // destination row of each token row: (window batch, head 0) base + token-in-window
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    sq_dest[i] = __builtin_amdgcn_raw_buffer_load_b32(rmap, (row0 + 4 * i) * 4u, 0, 0) + unsigned(sq_head * g.sam_npad);
             }
             if constexpr (EPI == EPI_CONV) {   // shortcut rows: (hi + lo) / 8; an empty descriptor (no residual) reads zeros
 #pragma unroll
@@ -363,6 +389,19 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
                 const unsigned off = (row0 + 4 * i) * c_row_bytes;
                 if constexpr (EPI == EPI_BIAS) {
                     v = v * inv + bias;
+                } else if constexpr (EPI == EPI_SAM_QKV) {
+                    v = (v * inv + bias) * sq_scale;
+                    pope_amax4x2(amax, v);
+                    const unsigned o = col_ok && row0 + 4 * i < unsigned(g.M) ? (sq_dest[i] * unsigned(sq_row_h) + unsigned(sq_c)) * 2u : DROP;
+                    if constexpr (PLAIN) {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, f16x4)), rsq, o, 0, 0);
+                    } else {
+                        f16x4 hi, lo;
+                        pope_split4(v, hi, lo);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rsq, o, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsq, o + unsigned(sq_lo) * 2u, 0, 0);
+                    }
+                    continue;
                 } else if constexpr (EPI == EPI_BIAS_GELU) {
                     v = v * inv + bias;
                     const f32x2 g01 = gelu_erf_pair(f32x2{v[0], v[1]}), g23 = gelu_erf_pair(f32x2{v[2], v[3]});
@@ -403,7 +442,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (OUT_PLANES) pope_range_flag(g.range_flag, g.range_bit, !(__builtin_fmaxf(amax[0], amax[1]) * A_SCALE < POPE_F16_OVERFLOW));
+        if constexpr (EPI == EPI_SAM_QKV)   // attention operands carry no scale
+            pope_range_flag(g.range_flag, g.range_bit, !(__builtin_fmaxf(amax[0], amax[1]) < POPE_F16_OVERFLOW));
+        else if constexpr (OUT_PLANES)
+            pope_range_flag(g.range_flag, g.range_bit, !(__builtin_fmaxf(amax[0], amax[1]) * A_SCALE < POPE_F16_OVERFLOW));
         __syncthreads();  // epilogue staging is drained before the stage is written again
     };
 
@@ -502,6 +544,11 @@ int launch16(const GemmParams& g, hipStream_t stream, int nbatch = 1) {
 // argument checks are the callers' (gemm_f16x3.hip: pope_launch_gemm_nt_f16x3_planes / pope_launch_sim_f16x3_planes)
 int pope_launch_planes16(const GemmParams& g, hipStream_t stream) {
     const bool out_planes = g.c_pl != nullptr;
+    if (g.epilogue == EPI_SAM_QKV) {
+        if (!g.sam_q || !g.sam_k || !g.sam_v || !g.sam_rowmap || g.sam_hd <= 0 || (g.sam_hd & 3) || (g.sam_dim & 63) || g.N != 3 * g.sam_dim)
+            return POPE_ERR_ARG;
+        return g.plain ? launch16<EPI_SAM_QKV, true, false, true>(g, stream) : launch16<EPI_SAM_QKV, true, false, false>(g, stream);
+    }
     if (g.plain) {   // single-product f16 (SAM encoder, precision "f16"): the four forms that path uses
         if (g.epilogue == EPI_BIAS && !out_planes) return launch16<EPI_BIAS, false, false, true>(g, stream);
         if (g.epilogue == EPI_BIAS_GELU && out_planes) return launch16<EPI_BIAS_GELU, true, false, true>(g, stream);

@@ -11,6 +11,7 @@ enum GemmEpilogue {
     EPI_POSB = 3,         // patch embed: C = im2col(img).W^T + posb[token]   (A = image)
     EPI_BIAS_RELU = 5,    // C = max(A.W^T + bias, 0)                (LoFTR encoder MLP, transformer.py:24-28; gemm_planes.hip only)
     EPI_SIM = 4,          // batched similarity (planes kernel): C[b] = (A[b].W[b]^T * alpha) / divisor, no bias
+    EPI_SAM_QKV = 7,      // SAM block's QKV projection written straight into the attention operand planes (sam.hip; gemm_planes.hip only)
     EPI_CONV = 6,         // C = act(A.W^T + bias [+ res_pl]), act(v) = max(v, 0) + act_slope * min(v, 0): ReLU (0), LeakyReLU
                           // (0.01) or identity (1); the ResNet-FPN convolutions (conv.hip; gemm_planes.hip only)
 };
@@ -74,6 +75,14 @@ struct GemmParams {
     // (value * scale); K, lda, ldw and a planes output's ldc are given in 64-bit column PAIRS (= real columns / 2, so
     // that a row's pitch is still ld * 4 bytes); N, ldc of an fp32 output, bias, gamma and res stay in real columns.
     int plain;
+    // EPI_SAM_QKV: C[t, which * dim + head * hd + c] (+ bias, q additionally * sam_qscale) goes to row
+    // sam_rowmap[t] + head * sam_npad, column c of sam_q / sam_k / sam_v (f16 hi/lo rows [DQ | DQ], [DQ | hd], [DV | DV];
+    // plain: the hi parts only) — the window partition of image_encoder.py:238-259 is that row map
+    void *sam_q, *sam_k, *sam_v;
+    unsigned sam_bytes[3];
+    const int* sam_rowmap;
+    int sam_hd, sam_dim, sam_npad, sam_dq, sam_dv;
+    float sam_qscale;
     // patch-embed gather (EPI_POSB)
     const float* posb;   // [ntok, N]: row 0 = cls_token + pos[0]; row n = conv bias + pos[n]
     int ntok, img_h, img_w, patch, grid_w;

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <utility>
 
 namespace {
 
@@ -110,7 +111,9 @@ __device__ __forceinline__ const float* sam_src(const float* qkv, const float* q
     return (y < a.g && x < a.g) ? qkv + ((size_t)b * a.g * a.g + (size_t)y * a.g + x) * 3 * a.dim + col : qkv_bias + col;
 }
 
-template <bool PLAIN>
+// PAD_ONLY (the fused path, where the QKV GEMM's epilogue writes the real tokens' rows itself — EPI_SAM_QKV): only the rows
+// of the zero-padded tokens of the edge windows are written (q, k, v = the qkv bias), nothing else is touched.
+template <bool PLAIN, bool PAD_ONLY>
 __global__ __launch_bounds__(256) void sam_attn_split_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                              _Float16* __restrict__ Qp, _Float16* __restrict__ Kp,
                                                              _Float16* __restrict__ Vp, AttnGeom a, unsigned* range_flag) {
@@ -128,6 +131,11 @@ __global__ __launch_bounds__(256) void sam_attn_split_kernel(const float* __rest
         const int n = int(row % a.Npad), grp = int(row / a.Npad);
         const int head = grp % a.heads, wb = grp / a.heads;
         const bool live = n < a.Nq;
+        if constexpr (PAD_ONLY) {
+            const int win = wb % (a.nw * a.nw), wy = win / a.nw, wx = win - wy * a.nw;
+            const bool pad = live && (wy * a.ws + n / a.ws >= a.g || wx * a.ws + n % a.ws >= a.g);
+            if (!pad || (piece >= 2 * hp && piece < 2 * hp + jp)) continue;
+        }
         if (piece >= 2 * hp && piece < 2 * hp + jp) {   // K' one-hot columns hd + 8 p ..: kh(n) = n / ws, kw(n) = n % ws
             const int c0 = 8 * (piece - 2 * hp);
             const int kh = n / a.ws, kw = n - kh * a.ws;
@@ -167,9 +175,33 @@ __global__ __launch_bounds__(256) void sam_attn_split_kernel(const float* __rest
     pope_range_flag(range_flag, POPE_RANGE_QKV, !(amax < POPE_F16_OVERFLOW));
 }
 
+// Fused path, once per forward pass and geometry (the operand buffers are zero-filled first): the one-hot columns of K'
+// (they depend on the token's position in its window only) ...
+__global__ __launch_bounds__(256) void sam_onehot_kernel(_Float16* __restrict__ Kp, AttnGeom a, int k_row) {
+    const int G = a.B * a.nw * a.nw * a.heads;
+    const long long total = (long long)G * a.Nq;
+    for (long long id = blockIdx.x * 256ll + threadIdx.x; id < total; id += 256ll * gridDim.x) {
+        const int n = int(id % a.Nq), grp = int(id / a.Nq);
+        _Float16* row = Kp + ((size_t)grp * a.Npad + n) * k_row + a.hd;
+        row[n / a.ws] = _Float16(1.0f);
+        row[a.ws + n % a.ws] = _Float16(1.0f);
+    }
+}
+// ... and the window partition (image_encoder.py:238-259) as a row map for the QKV GEMM's epilogue:
+// map[token row t] = (window batch * heads) * Npad + position of the token in its window
+__global__ __launch_bounds__(256) void sam_rowmap_kernel(int* __restrict__ map, AttnGeom a) {
+    const int rows = a.B * a.g * a.g;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < rows; t += 256 * gridDim.x) {
+        const int x = t % a.g, y = (t / a.g) % a.g, b = t / (a.g * a.g);
+        const int wy = y / a.ws, wx = x / a.ws;
+        map[t] = ((b * a.nw + wy) * a.nw + wx) * a.heads * a.Npad + (y - wy * a.ws) * a.ws + (x - wx * a.ws);
+    }
+}
+
 // Rh / Rw: [ws][ws][hd] fp32, the gathered tables get_rel_pos returns (image_encoder.py:288-316; host, once per model).
 // Workgroup = TPB = 256 / JT tokens of one window batch (JT = DQ - hd = 32 or 128 columns: 2 ws live ones, zeros behind).
-template <int HD, bool PLAIN>
+// FROM_QP (fused path): q is read back from the Q' rows the QKV epilogue wrote (q * scale * log2 e as hi [+ lo]).
+template <int HD, bool PLAIN, bool FROM_QP>
 __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                               const float* __restrict__ Rh, const float* __restrict__ Rw,
                                                               _Float16* __restrict__ Qp, AttnGeom a, unsigned* range_flag) {
@@ -182,7 +214,15 @@ __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __res
         const int head = rem / (HD / 4), c = (rem - head * (HD / 4)) * 4;
         const int n = n0 + tt;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < a.Nq) v = *reinterpret_cast<const f32x4*>(sam_src(qkv, qkv_bias, a, wb, n, 0, head) + c);
+        if (n < a.Nq) {
+            if constexpr (FROM_QP) {
+                const _Float16* qr = Qp + ((size_t)(wb * a.heads + head) * a.Npad + n) * (PLAIN ? a.DQ : 2 * a.DQ) + c;
+                v = __builtin_convertvector(*reinterpret_cast<const f16x4*>(qr), f32x4);
+                if constexpr (!PLAIN) v = v + __builtin_convertvector(*reinterpret_cast<const f16x4*>(qr + a.DQ), f32x4);
+            } else {
+                v = *reinterpret_cast<const f32x4*>(sam_src(qkv, qkv_bias, a, wb, n, 0, head) + c);
+            }
+        }
         *reinterpret_cast<f32x4*>(&sq[(tt * a.heads + head) * HD + c]) = v;
     }
     __syncthreads();
@@ -210,7 +250,7 @@ __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __res
                 acc2[1] = __builtin_elementwise_fma(f32x2{q4[2], q4[3]}, f32x2{R[c][2], R[c][3]}, acc2[1]);
             }
             float acc = (acc2[0][0] + acc2[0][1]) + (acc2[1][0] + acc2[1][1]);
-            acc *= L2E;
+            acc *= FROM_QP ? sqrtf(float(HD)) : L2E;   // FROM_QP: q already carries scale * log2 e, undo the scale
             amax = fmaxf(amax, fabsf(acc));
             if (!(acc == acc)) amax = INFINITY;
             const _Float16 hi = _Float16(acc);
@@ -667,13 +707,12 @@ size_t pope_sam_encoder_workspace(const SamEncParams& q) {
     size_t big = rows * 4 * q.dim * 4;                      // qkv fp32 [rows, 3 dim] + attention output planes [rows, dim]
     if (rows * q.hidden * 4 > big) big = rows * q.hidden * 4;   // fc1 output planes
     if (rows * kp * 4 > big) big = rows * kp * 4;               // im2col planes
-    size_t ops = 0;
+    size_t ops = 0;   // one operand set per geometry (window, global): their constant parts are written once per forward pass
     for (int pass = 0; pass < 2; ++pass) {
         AttnPlan p;
         const int ws = pass ? g : (q.window > 0 ? q.window : g);
         if (!plan_attention(q.B, g, ws, q.heads, hd, p)) return 0;
-        const size_t need = align256(p.qp) + align256(p.kp) + align256(p.vp);
-        if (need > ops) ops = need;
+        ops += align256(p.qp) + align256(p.kp) + align256(p.vp) + align256(rows * sizeof(int));
     }
     const size_t gp = size_t(g) + 2;
     return align256(rows * q.dim * 4) /* x */ + align256(rows * q.dim * 4) /* xn planes */ + align256(big) + ops +
@@ -713,12 +752,14 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
     float* qkv = reinterpret_cast<float*>(big);
     void* att_pl = big + size_t(rows) * 3 * dim * 4;
     void* hid_pl = big;
-    size_t ops = 0;
-    for (const AttnPlan* p : {&plan_w, &plan_g}) {
-        const size_t n = align256(p->qp) + align256(p->kp) + align256(p->vp);
-        if (n > ops) ops = n;
+    struct OpSet { _Float16 *q, *k, *v; int* map; };
+    OpSet ops_w, ops_g;
+    for (auto pr : {std::make_pair(&plan_w, &ops_w), std::make_pair(&plan_g, &ops_g)}) {
+        pr.second->q = reinterpret_cast<_Float16*>(take(pr.first->qp));
+        pr.second->k = reinterpret_cast<_Float16*>(take(pr.first->kp));
+        pr.second->v = reinterpret_cast<_Float16*>(take(pr.first->vp));
+        pr.second->map = reinterpret_cast<int*>(take(size_t(rows) * sizeof(int)));
     }
-    char* op_base = take(ops);
     float* t1 = reinterpret_cast<float*>(take(size_t(rows) * oc * 4));
     void* t1_pl = take(brows * oc * 4);
     float* t2 = reinterpret_cast<float*>(take(brows * oc * 4));
@@ -762,32 +803,91 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
         if (q.pos) POPE_TRY(gemm(big, q.patch_wp, q.patch_b, x, nullptr, dim, kp, EPI_BIAS_LS_RES, q.ones, q.pos, g * g));
         else POPE_TRY(gemm(big, q.patch_wp, q.patch_b, x, nullptr, dim, kp, EPI_BIAS, nullptr, nullptr, 0));
     }
+    // Fused operand path (default; POPE_SAM_NO_FUSED_QKV=1 = the separate split kernel, for A/B runs): the QKV GEMM's
+    // epilogue writes q * scale, k, v into the attention operand rows.  What does not depend on the block — zero rows and
+    // columns, K's one-hot columns, the window partition's row map — is written here, once per forward pass and geometry.
+    static const bool no_fuse = getenv("POPE_SAM_NO_FUSED_QKV") && atoi(getenv("POPE_SAM_NO_FUSED_QKV"));
+    const bool fused_qkv = !no_fuse && !(dim & 63);
+    if (fused_qkv) {
+        bool use[2] = {false, false};
+        for (int i = 0; i < q.depth; ++i) use[(q.blocks[i].global || q.window <= 0) ? 1 : 0] = true;
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (!use[s2]) continue;
+            const AttnPlan& p = s2 ? plan_g : plan_w;
+            const OpSet& os = s2 ? ops_g : ops_w;
+            if (hipMemsetAsync(os.q, 0, p.qp, stream) != hipSuccess || hipMemsetAsync(os.k, 0, p.kp, stream) != hipSuccess ||
+                hipMemsetAsync(os.v, 0, p.vp, stream) != hipSuccess)
+                return POPE_ERR_LAUNCH;
+            const AttnGeom& a = p.geom;
+            const int k_row = plain ? a.DQ : a.DQ + a.HDP;
+            hipLaunchKernelGGL(sam_onehot_kernel, dim3(grid_for((long long)a.B * a.nw * a.nw * a.heads * a.Nq)), dim3(256), 0, stream,
+                               os.k, a, k_row);
+            POPE_TRY(pope_check_launch());
+            hipLaunchKernelGGL(sam_rowmap_kernel, dim3(grid_for(rows)), dim3(256), 0, stream, os.map, a);
+            POPE_TRY(pope_check_launch());
+        }
+    }
     for (int i = 0; i < q.depth; ++i) {
         const SamBlockParams& k = q.blocks[i];
         if (!k.norm1_w || !k.norm1_b || !k.qkv_wp || !k.qkv_b || !k.proj_wp || !k.proj_b || !k.norm2_w || !k.norm2_b || !k.fc1_wp ||
             !k.fc1_b || !k.fc2_wp || !k.fc2_b || !k.rel_h || !k.rel_w)
             return POPE_ERR_ARG;
-        const AttnPlan& p = k.global || q.window <= 0 ? plan_g : plan_w;
+        const bool glob = k.global || q.window <= 0;
+        const AttnPlan& p = glob ? plan_g : plan_w;
+        const OpSet& os = glob ? ops_g : ops_w;
         const AttnGeom& a = p.geom;
         // x = x + attn(norm1(x))                                         image_encoder.py:166-179
         POPE_TRY(layernorm(k.norm1_w, k.norm1_b));
-        POPE_TRY(gemm(xn_pl, k.qkv_wp, k.qkv_b, qkv, nullptr, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, 0));
-        _Float16* Qp = reinterpret_cast<_Float16*>(op_base);
-        _Float16* Kp = reinterpret_cast<_Float16*>(op_base + align256(p.qp));
-        _Float16* Vp = reinterpret_cast<_Float16*>(op_base + align256(p.qp) + align256(p.kp));
+        _Float16 *Qp = os.q, *Kp = os.k, *Vp = os.v;
         const int G = a.B * a.nw * a.nw * a.heads;
-        {
+        if (fused_qkv) {
+            // QKV projection written straight into the operand rows (EPI_SAM_QKV: window partition = os.map, q * scale *
+            // log2 e), the pad tokens' rows from the bias, then the relative-position columns from the Q' rows
+            GemmParams gq = {};
+            gq.range_flag = flag; gq.range_bit = POPE_RANGE_QKV;
+            gq.a_pl = xn_pl; gq.w_pl = k.qkv_wp; gq.bias = k.qkv_b; gq.c_pl = Qp;
+            const int Kc = plain ? dim / 2 : dim;
+            gq.lda = Kc; gq.ldw = Kc; gq.K = Kc; gq.ldc = 32; gq.M = rows; gq.N = 3 * dim;
+            gq.epilogue = EPI_SAM_QKV; gq.plain = plain;
+            gq.sam_q = Qp; gq.sam_k = Kp; gq.sam_v = Vp; gq.sam_rowmap = os.map;
+            gq.sam_bytes[0] = unsigned(p.qp); gq.sam_bytes[1] = unsigned(p.kp); gq.sam_bytes[2] = unsigned(p.vp);
+            gq.sam_hd = hd; gq.sam_dim = dim; gq.sam_npad = a.Npad; gq.sam_dq = a.DQ; gq.sam_dv = a.DV;
+            gq.sam_qscale = 1.0f / sqrtf(float(hd)) * L2E;
+            POPE_TRY(pope_launch_planes16(gq, stream));
+            if (a.nw * a.ws > a.g) {   // edge windows hold zero-padded tokens: their q, k, v are the bias
+                const long long total = (long long)G * a.Npad * (2 * (hd / 8) + (a.DQ - hd) / 8 + a.DV / 8);
+                if (plain)
+                    hipLaunchKernelGGL((sam_attn_split_kernel<true, true>), dim3(grid_for(total)), dim3(256), 0, stream, nullptr, k.qkv_b,
+                                       Qp, Kp, Vp, a, flag);
+                else
+                    hipLaunchKernelGGL((sam_attn_split_kernel<false, true>), dim3(grid_for(total)), dim3(256), 0, stream, nullptr, k.qkv_b,
+                                       Qp, Kp, Vp, a, flag);
+                POPE_TRY(pope_check_launch());
+            }
+            const int tpb = 256 / (a.DQ - hd);
+            const dim3 rgrid((a.Npad + tpb - 1) / tpb, a.B * a.nw * a.nw);
+            const size_t lds = size_t(tpb) * dim * sizeof(float);
+#define POPE_SAM_RELPOS(HD, PL) \
+    hipLaunchKernelGGL((sam_attn_relpos_kernel<HD, PL, true>), rgrid, dim3(256), lds, stream, nullptr, k.qkv_b, k.rel_h, k.rel_w, Qp, a, flag)
+            if (hd == 80) { if (plain) POPE_SAM_RELPOS(80, true); else POPE_SAM_RELPOS(80, false); }
+            else { if (plain) POPE_SAM_RELPOS(64, true); else POPE_SAM_RELPOS(64, false); }
+#undef POPE_SAM_RELPOS
+            POPE_TRY(pope_check_launch());
+        } else {
+            POPE_TRY(gemm(xn_pl, k.qkv_wp, k.qkv_b, qkv, nullptr, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, 0));
             const long long total = (long long)G * a.Npad * (2 * (hd / 8) + (a.DQ - hd) / 8 + a.DV / 8);
             if (plain)
-                hipLaunchKernelGGL(sam_attn_split_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, qkv, k.qkv_b, Qp, Kp, Vp, a, flag);
+                hipLaunchKernelGGL((sam_attn_split_kernel<true, false>), dim3(grid_for(total)), dim3(256), 0, stream, qkv, k.qkv_b, Qp, Kp,
+                                   Vp, a, flag);
             else
-                hipLaunchKernelGGL(sam_attn_split_kernel<false>, dim3(grid_for(total)), dim3(256), 0, stream, qkv, k.qkv_b, Qp, Kp, Vp, a, flag);
+                hipLaunchKernelGGL((sam_attn_split_kernel<false, false>), dim3(grid_for(total)), dim3(256), 0, stream, qkv, k.qkv_b, Qp, Kp,
+                                   Vp, a, flag);
             POPE_TRY(pope_check_launch());
             const int tpb = 256 / (a.DQ - hd);
             const dim3 rgrid((a.Npad + tpb - 1) / tpb, a.B * a.nw * a.nw);
             const size_t lds = size_t(tpb) * dim * sizeof(float);
 #define POPE_SAM_RELPOS(HD, PL) \
-    hipLaunchKernelGGL((sam_attn_relpos_kernel<HD, PL>), rgrid, dim3(256), lds, stream, qkv, k.qkv_b, k.rel_h, k.rel_w, Qp, a, flag)
+    hipLaunchKernelGGL((sam_attn_relpos_kernel<HD, PL, false>), rgrid, dim3(256), lds, stream, qkv, k.qkv_b, k.rel_h, k.rel_w, Qp, a, flag)
             if (hd == 80) { if (plain) POPE_SAM_RELPOS(80, true); else POPE_SAM_RELPOS(80, false); }
             else { if (plain) POPE_SAM_RELPOS(64, true); else POPE_SAM_RELPOS(64, false); }
 #undef POPE_SAM_RELPOS
