@@ -8,8 +8,8 @@
 //     K'[m] = [ k[m]       | onehot(kh(m))          | onehot(kw(m))          ]
 // so Q'.K'^T is the biased score and the flash kernel needs no bias path at all: the relative-position terms ride on
 // the matrix cores (K' one-hot columns are exact in f16 and have no lo plane: 2 MFMAs per step there instead of 3).
-// `sam_attn_split_kernel` + `sam_attn_relpos_kernel` build Q', K', V as f16 hi/lo planes per (window, head) straight from
-// the QKV GEMM's fp32 output — they also do the window partition, and the zero-padded tokens of the bottom / right windows
+// The QKV GEMM's epilogue (gemm_planes.hip, EPI_SAM_QKV), `sam_pad_tokens_kernel` and `sam_attn_relpos_kernel` build Q', K', V
+// as f16 hi/lo planes per (window, head) — the window partition is a row map of the epilogue, and the zero-padded tokens of the bottom / right windows
 // (image_encoder.py:251-254, padded AFTER norm1) get k = v = the qkv bias, exactly what Linear(0) gives the reference.
 // `sam_attn_kernel` is the single-stage f16x3 flash kernel of attention_f16x3.hip re-cut for 32-key tiles, a
 // K depth of 16 * NSTEP and 32 * DVT value columns; its epilogue un-partitions (drops the pad queries) and writes the
@@ -94,74 +94,43 @@ struct AttnGeom {
 };
 
 // Operand planes of one block's attention (halves; G = B nw^2 heads groups, n = token inside its window):
-//   Qp [G][Npad][DQ hi | DQ lo], Kp [G][Npad][DQ hi | hd lo], Vp [G][Npad][DV hi | DV lo]
-// Rows Nq..Npad are written as zeros every time (the buffers are shared by the window and the global geometry).
-// Two kernels.  `sam_attn_split_kernel` streams: per (group, row) it converts q * scale, k and v (8 columns per thread,
-// 32-byte reads, 16-byte stores) and writes K's one-hot columns.  `sam_attn_relpos_kernel` computes the relative
-// position columns of Q': R[q][k][:] depends on the token, not on the head, so a thread owns one (token, k) pair,
-// keeps that row of Rh / Rw (hd floats) in registers and walks the heads with q broadcast from LDS — every table row
-// is read once per token instead of once per (token, head).
-__device__ __forceinline__ const float* sam_src(const float* qkv, const float* qkv_bias, const AttnGeom& a, int wb, int n, int which,
-                                                int head) {
-    const int win = wb % (a.nw * a.nw), b = wb / (a.nw * a.nw);
-    const int wy = win / a.nw, wx = win - wy * a.nw;
-    const int y = wy * a.ws + n / a.ws, x = wx * a.ws + n % a.ws;
-    const int col = which * a.dim + head * a.hd;
-    // tokens padded in by window_partition are zeros AFTER norm1 (image_encoder.py:173-174): Linear(0) = bias
-    return (y < a.g && x < a.g) ? qkv + ((size_t)b * a.g * a.g + (size_t)y * a.g + x) * 3 * a.dim + col : qkv_bias + col;
-}
-
-// PAD_ONLY (the fused path, where the QKV GEMM's epilogue writes the real tokens' rows itself — EPI_SAM_QKV): only the rows
-// of the zero-padded tokens of the edge windows are written (q, k, v = the qkv bias), nothing else is touched.
-template <bool PLAIN, bool PAD_ONLY>
-__global__ __launch_bounds__(256) void sam_attn_split_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
-                                                             _Float16* __restrict__ Qp, _Float16* __restrict__ Kp,
-                                                             _Float16* __restrict__ Vp, AttnGeom a, unsigned* range_flag) {
+//   Qp [G][Npad][DQ hi | DQ lo], Kp [G][Npad][DQ hi | hd lo], Vp [G][Npad][DV hi | DV lo]     (PLAIN: the hi parts only)
+// Who writes what: the QKV GEMM's epilogue (gemm_planes.hip, EPI_SAM_QKV) writes q * scale * log2 e, k and v of every real
+// token into its rows — the window partition is a row map; `sam_pad_tokens_kernel` writes the rows of the zero-padded
+// tokens of the edge windows (image_encoder.py:251-254: padded AFTER norm1, so their q, k, v are the qkv bias);
+// `sam_attn_relpos_kernel` adds the relative-position columns of Q'; everything that does not depend on the block
+// (zero rows n >= Nq, zero value columns hd..DV, K's one-hot columns, the row map) is written once per forward pass.
+template <bool PLAIN>
+__global__ __launch_bounds__(256) void sam_pad_tokens_kernel(const float* __restrict__ qkv_bias, _Float16* __restrict__ Qp,
+                                                             _Float16* __restrict__ Kp, _Float16* __restrict__ Vp, AttnGeom a,
+                                                             unsigned* range_flag) {
     // row pitches (halves): PLAIN rows carry no lo halves
     const int q_row = PLAIN ? a.DQ : 2 * a.DQ, k_row = PLAIN ? a.DQ : a.DQ + a.HDP, v_row = PLAIN ? a.DV : 2 * a.DV;
-    const int hp = a.hd / 8, jp = (a.DQ - a.hd) / 8, vp = a.DV / 8;
-    const int per_row = 2 * hp + jp + vp;   // q pieces | k pieces | one-hot pieces | v pieces
+    const int hp = a.hd / 8;   // 8-column pieces of q | k | v per (group, token)
     const int G = a.B * a.nw * a.nw * a.heads;
-    const long long total = (long long)G * a.Npad * per_row;
+    const long long total = (long long)G * a.Nq * 3 * hp;
     const float scale = 1.0f / sqrtf(float(a.hd)) * L2E;   // head_dim ** -0.5 (image_encoder.py:206), log2 domain
     float amax = 0.f;
     for (long long id = blockIdx.x * 256ll + threadIdx.x; id < total; id += 256ll * gridDim.x) {
-        const int piece = int(id % per_row);
-        const long long row = id / per_row;   // grp * Npad + n
-        const int n = int(row % a.Npad), grp = int(row / a.Npad);
+        const int piece = int(id % (3 * hp));
+        const long long gn = id / (3 * hp);
+        const int n = int(gn % a.Nq), grp = int(gn / a.Nq);
         const int head = grp % a.heads, wb = grp / a.heads;
-        const bool live = n < a.Nq;
-        if constexpr (PAD_ONLY) {
-            const int win = wb % (a.nw * a.nw), wy = win / a.nw, wx = win - wy * a.nw;
-            const bool pad = live && (wy * a.ws + n / a.ws >= a.g || wx * a.ws + n % a.ws >= a.g);
-            if (!pad || (piece >= 2 * hp && piece < 2 * hp + jp)) continue;
-        }
-        if (piece >= 2 * hp && piece < 2 * hp + jp) {   // K' one-hot columns hd + 8 p ..: kh(n) = n / ws, kw(n) = n % ws
-            const int c0 = 8 * (piece - 2 * hp);
-            const int kh = n / a.ws, kw = n - kh * a.ws;
-            f16x8 v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (live && (c0 + e == kh || c0 + e == a.ws + kw)) ? _Float16(1.0f) : _Float16(0.0f);
-            *reinterpret_cast<f16x8*>(Kp + (size_t)row * k_row + a.hd + c0) = v;
-            continue;
-        }
-        const int which = piece < hp ? 0 : (piece < 2 * hp ? 1 : 2);
-        const int c0 = 8 * (which == 0 ? piece : (which == 1 ? piece - hp : piece - 2 * hp - jp));
-        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-        if (live && c0 < a.hd) {
-            const float* src = sam_src(qkv, qkv_bias, a, wb, n, which, head) + c0;
-            v0 = *reinterpret_cast<const f32x4*>(src);
-            v1 = *reinterpret_cast<const f32x4*>(src + 4);
-        }
+        const int win = wb % (a.nw * a.nw), wy = win / a.nw, wx = win - wy * a.nw;
+        if (wy * a.ws + n / a.ws < a.g && wx * a.ws + n % a.ws < a.g) continue;   // a real token: the GEMM wrote it
+        const int which = piece / hp, c0 = 8 * (piece - which * hp);
+        const float* src = qkv_bias + which * a.dim + head * a.hd + c0;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
         if (which == 0) { v0 = v0 * scale; v1 = v1 * scale; }
         amax = pope_amax4(pope_amax4(amax, v0), v1);
         const float s8 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
         if (!(s8 == s8)) amax = INFINITY;
+        const size_t row = (size_t)grp * a.Npad + n;
         _Float16* hi_dst;
         _Float16* lo_dst;
-        if (which == 0) { hi_dst = Qp + (size_t)row * q_row + c0; lo_dst = hi_dst + a.DQ; }
-        else if (which == 1) { hi_dst = Kp + (size_t)row * k_row + c0; lo_dst = hi_dst + a.DQ; }
-        else { hi_dst = Vp + (size_t)row * v_row + c0; lo_dst = hi_dst + a.DV; }
+        if (which == 0) { hi_dst = Qp + row * q_row + c0; lo_dst = hi_dst + a.DQ; }
+        else if (which == 1) { hi_dst = Kp + row * k_row + c0; lo_dst = hi_dst + a.DQ; }
+        else { hi_dst = Vp + row * v_row + c0; lo_dst = hi_dst + a.DV; }
         if constexpr (PLAIN) {
             *reinterpret_cast<f16x8*>(hi_dst) = cat(__builtin_convertvector(v0, f16x4), __builtin_convertvector(v1, f16x4));
         } else {
@@ -175,7 +144,7 @@ __global__ __launch_bounds__(256) void sam_attn_split_kernel(const float* __rest
     pope_range_flag(range_flag, POPE_RANGE_QKV, !(amax < POPE_F16_OVERFLOW));
 }
 
-// Fused path, once per forward pass and geometry (the operand buffers are zero-filled first): the one-hot columns of K'
+// Once per forward pass and geometry (the operand buffers are zero-filled first): the one-hot columns of K'
 // (they depend on the token's position in its window only) ...
 __global__ __launch_bounds__(256) void sam_onehot_kernel(_Float16* __restrict__ Kp, AttnGeom a, int k_row) {
     const int G = a.B * a.nw * a.nw * a.heads;
@@ -200,10 +169,9 @@ __global__ __launch_bounds__(256) void sam_rowmap_kernel(int* __restrict__ map, 
 
 // Rh / Rw: [ws][ws][hd] fp32, the gathered tables get_rel_pos returns (image_encoder.py:288-316; host, once per model).
 // Workgroup = TPB = 256 / JT tokens of one window batch (JT = DQ - hd = 32 or 128 columns: 2 ws live ones, zeros behind).
-// FROM_QP (fused path): q is read back from the Q' rows the QKV epilogue wrote (q * scale * log2 e as hi [+ lo]).
-template <int HD, bool PLAIN, bool FROM_QP>
-__global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
-                                                              const float* __restrict__ Rh, const float* __restrict__ Rw,
+// q is read back from the Q' rows the QKV epilogue (and the pad-token kernel) wrote: q * scale * log2 e as hi [+ lo].
+template <int HD, bool PLAIN>
+__global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __restrict__ Rh, const float* __restrict__ Rw,
                                                               _Float16* __restrict__ Qp, AttnGeom a, unsigned* range_flag) {
     extern __shared__ __attribute__((aligned(16))) float sq[];   // [TPB][heads * HD]
     const int JT = a.DQ - HD, TPB = 256 / JT;
@@ -215,13 +183,9 @@ __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __res
         const int n = n0 + tt;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (n < a.Nq) {
-            if constexpr (FROM_QP) {
-                const _Float16* qr = Qp + ((size_t)(wb * a.heads + head) * a.Npad + n) * (PLAIN ? a.DQ : 2 * a.DQ) + c;
-                v = __builtin_convertvector(*reinterpret_cast<const f16x4*>(qr), f32x4);
-                if constexpr (!PLAIN) v = v + __builtin_convertvector(*reinterpret_cast<const f16x4*>(qr + a.DQ), f32x4);
-            } else {
-                v = *reinterpret_cast<const f32x4*>(sam_src(qkv, qkv_bias, a, wb, n, 0, head) + c);
-            }
+            const _Float16* qr = Qp + ((size_t)(wb * a.heads + head) * a.Npad + n) * (PLAIN ? a.DQ : 2 * a.DQ) + c;
+            v = __builtin_convertvector(*reinterpret_cast<const f16x4*>(qr), f32x4);
+            if constexpr (!PLAIN) v = v + __builtin_convertvector(*reinterpret_cast<const f16x4*>(qr + a.DQ), f32x4);
         }
         *reinterpret_cast<f32x4*>(&sq[(tt * a.heads + head) * HD + c]) = v;
     }
@@ -250,7 +214,7 @@ __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __res
                 acc2[1] = __builtin_elementwise_fma(f32x2{q4[2], q4[3]}, f32x2{R[c][2], R[c][3]}, acc2[1]);
             }
             float acc = (acc2[0][0] + acc2[0][1]) + (acc2[1][0] + acc2[1][1]);
-            acc *= FROM_QP ? sqrtf(float(HD)) : L2E;   // FROM_QP: q already carries scale * log2 e, undo the scale
+            acc *= sqrtf(float(HD));   // q carries scale * log2 e: undo the scale
             amax = fmaxf(amax, fabsf(acc));
             if (!(acc == acc)) amax = INFINITY;
             const _Float16 hi = _Float16(acc);
@@ -704,7 +668,7 @@ size_t pope_sam_encoder_workspace(const SamEncParams& q) {
     const int g = q.img / q.patch, hd = q.dim / q.heads;
     const size_t rows = size_t(q.B) * g * g;
     const size_t kp = size_t(3) * q.patch * q.patch;
-    size_t big = rows * 4 * q.dim * 4;                      // qkv fp32 [rows, 3 dim] + attention output planes [rows, dim]
+    size_t big = rows * 4 * q.dim * 4;                      // attention output planes [rows, dim] (room for 4 dim: mlp_ratio 4)
     if (rows * q.hidden * 4 > big) big = rows * q.hidden * 4;   // fc1 output planes
     if (rows * kp * 4 > big) big = rows * kp * 4;               // im2col planes
     size_t ops = 0;   // one operand set per geometry (window, global): their constant parts are written once per forward pass
@@ -749,8 +713,7 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
     if (size_t(rows) * hidden * 4 > big_bytes) big_bytes = size_t(rows) * hidden * 4;
     if (size_t(rows) * kp * 4 > big_bytes) big_bytes = size_t(rows) * kp * 4;
     char* big = take(big_bytes);
-    float* qkv = reinterpret_cast<float*>(big);
-    void* att_pl = big + size_t(rows) * 3 * dim * 4;
+    void* att_pl = big;   // attention output (the proj GEMM's operand); fc1's output reuses the buffer
     void* hid_pl = big;
     struct OpSet { _Float16 *q, *k, *v; int* map; };
     OpSet ops_w, ops_g;
@@ -803,12 +766,10 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
         if (q.pos) POPE_TRY(gemm(big, q.patch_wp, q.patch_b, x, nullptr, dim, kp, EPI_BIAS_LS_RES, q.ones, q.pos, g * g));
         else POPE_TRY(gemm(big, q.patch_wp, q.patch_b, x, nullptr, dim, kp, EPI_BIAS, nullptr, nullptr, 0));
     }
-    // Fused operand path (default; POPE_SAM_NO_FUSED_QKV=1 = the separate split kernel, for A/B runs): the QKV GEMM's
-    // epilogue writes q * scale, k, v into the attention operand rows.  What does not depend on the block — zero rows and
-    // columns, K's one-hot columns, the window partition's row map — is written here, once per forward pass and geometry.
-    static const bool no_fuse = getenv("POPE_SAM_NO_FUSED_QKV") && atoi(getenv("POPE_SAM_NO_FUSED_QKV"));
-    const bool fused_qkv = !no_fuse && !(dim & 63);
-    if (fused_qkv) {
+    // The QKV GEMM's epilogue writes q * scale, k, v into the attention operand rows (EPI_SAM_QKV).  What does not depend on
+    // the block — zero rows and columns, K's one-hot columns, the window partition's row map — is written here, once per
+    // forward pass and geometry.
+    {
         bool use[2] = {false, false};
         for (int i = 0; i < q.depth; ++i) use[(q.blocks[i].global || q.window <= 0) ? 1 : 0] = true;
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -840,9 +801,8 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
         POPE_TRY(layernorm(k.norm1_w, k.norm1_b));
         _Float16 *Qp = os.q, *Kp = os.k, *Vp = os.v;
         const int G = a.B * a.nw * a.nw * a.heads;
-        if (fused_qkv) {
-            // QKV projection written straight into the operand rows (EPI_SAM_QKV: window partition = os.map, q * scale *
-            // log2 e), the pad tokens' rows from the bias, then the relative-position columns from the Q' rows
+        {
+            // QKV projection written straight into the operand rows (window partition = os.map, q * scale * log2 e) ...
             GemmParams gq = {};
             gq.range_flag = flag; gq.range_bit = POPE_RANGE_QKV;
             gq.a_pl = xn_pl; gq.w_pl = k.qkv_wp; gq.bias = k.qkv_b; gq.c_pl = Qp;
@@ -854,40 +814,20 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
             gq.sam_hd = hd; gq.sam_dim = dim; gq.sam_npad = a.Npad; gq.sam_dq = a.DQ; gq.sam_dv = a.DV;
             gq.sam_qscale = 1.0f / sqrtf(float(hd)) * L2E;
             POPE_TRY(pope_launch_planes16(gq, stream));
-            if (a.nw * a.ws > a.g) {   // edge windows hold zero-padded tokens: their q, k, v are the bias
-                const long long total = (long long)G * a.Npad * (2 * (hd / 8) + (a.DQ - hd) / 8 + a.DV / 8);
+            if (a.nw * a.ws > a.g) {   // ... the rows of the edge windows' zero-padded tokens from the bias ...
+                const long long total = (long long)G * a.Nq * 3 * (hd / 8);
                 if (plain)
-                    hipLaunchKernelGGL((sam_attn_split_kernel<true, true>), dim3(grid_for(total)), dim3(256), 0, stream, nullptr, k.qkv_b,
-                                       Qp, Kp, Vp, a, flag);
+                    hipLaunchKernelGGL(sam_pad_tokens_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, k.qkv_b, Qp, Kp, Vp, a, flag);
                 else
-                    hipLaunchKernelGGL((sam_attn_split_kernel<false, true>), dim3(grid_for(total)), dim3(256), 0, stream, nullptr, k.qkv_b,
-                                       Qp, Kp, Vp, a, flag);
+                    hipLaunchKernelGGL(sam_pad_tokens_kernel<false>, dim3(grid_for(total)), dim3(256), 0, stream, k.qkv_b, Qp, Kp, Vp, a, flag);
                 POPE_TRY(pope_check_launch());
             }
+            // ... and the relative-position columns of Q' from the Q' rows
             const int tpb = 256 / (a.DQ - hd);
             const dim3 rgrid((a.Npad + tpb - 1) / tpb, a.B * a.nw * a.nw);
             const size_t lds = size_t(tpb) * dim * sizeof(float);
 #define POPE_SAM_RELPOS(HD, PL) \
-    hipLaunchKernelGGL((sam_attn_relpos_kernel<HD, PL, true>), rgrid, dim3(256), lds, stream, nullptr, k.qkv_b, k.rel_h, k.rel_w, Qp, a, flag)
-            if (hd == 80) { if (plain) POPE_SAM_RELPOS(80, true); else POPE_SAM_RELPOS(80, false); }
-            else { if (plain) POPE_SAM_RELPOS(64, true); else POPE_SAM_RELPOS(64, false); }
-#undef POPE_SAM_RELPOS
-            POPE_TRY(pope_check_launch());
-        } else {
-            POPE_TRY(gemm(xn_pl, k.qkv_wp, k.qkv_b, qkv, nullptr, 3 * dim, dim, EPI_BIAS, nullptr, nullptr, 0));
-            const long long total = (long long)G * a.Npad * (2 * (hd / 8) + (a.DQ - hd) / 8 + a.DV / 8);
-            if (plain)
-                hipLaunchKernelGGL((sam_attn_split_kernel<true, false>), dim3(grid_for(total)), dim3(256), 0, stream, qkv, k.qkv_b, Qp, Kp,
-                                   Vp, a, flag);
-            else
-                hipLaunchKernelGGL((sam_attn_split_kernel<false, false>), dim3(grid_for(total)), dim3(256), 0, stream, qkv, k.qkv_b, Qp, Kp,
-                                   Vp, a, flag);
-            POPE_TRY(pope_check_launch());
-            const int tpb = 256 / (a.DQ - hd);
-            const dim3 rgrid((a.Npad + tpb - 1) / tpb, a.B * a.nw * a.nw);
-            const size_t lds = size_t(tpb) * dim * sizeof(float);
-#define POPE_SAM_RELPOS(HD, PL) \
-    hipLaunchKernelGGL((sam_attn_relpos_kernel<HD, PL, false>), rgrid, dim3(256), lds, stream, qkv, k.qkv_b, k.rel_h, k.rel_w, Qp, a, flag)
+    hipLaunchKernelGGL((sam_attn_relpos_kernel<HD, PL>), rgrid, dim3(256), lds, stream, k.rel_h, k.rel_w, Qp, a, flag)
             if (hd == 80) { if (plain) POPE_SAM_RELPOS(80, true); else POPE_SAM_RELPOS(80, false); }
             else { if (plain) POPE_SAM_RELPOS(64, true); else POPE_SAM_RELPOS(64, false); }
 #undef POPE_SAM_RELPOS
