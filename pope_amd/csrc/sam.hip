@@ -107,17 +107,24 @@ __global__ __launch_bounds__(256) void sam_pad_tokens_kernel(const float* __rest
     // row pitches (halves): PLAIN rows carry no lo halves
     const int q_row = PLAIN ? a.DQ : 2 * a.DQ, k_row = PLAIN ? a.DQ : a.DQ + a.HDP, v_row = PLAIN ? a.DV : 2 * a.DV;
     const int hp = a.hd / 8;   // 8-column pieces of q | k | v per (group, token)
-    const int G = a.B * a.nw * a.nw * a.heads;
-    const long long total = (long long)G * a.Nq * 3 * hp;
+    // the pad tokens of one image, enumerated: the bottom strip (rows g .. gp of the padded gp x gp grid), then the right
+    // strip of the rows above it
+    const int gp = a.nw * a.ws, pr = gp - a.g, n_pad = gp * gp - a.g * a.g;
+    const long long total = (long long)a.B * n_pad * a.heads * 3 * hp;
     const float scale = 1.0f / sqrtf(float(a.hd)) * L2E;   // head_dim ** -0.5 (image_encoder.py:206), log2 domain
     float amax = 0.f;
     for (long long id = blockIdx.x * 256ll + threadIdx.x; id < total; id += 256ll * gridDim.x) {
         const int piece = int(id % (3 * hp));
-        const long long gn = id / (3 * hp);
-        const int n = int(gn % a.Nq), grp = int(gn / a.Nq);
-        const int head = grp % a.heads, wb = grp / a.heads;
-        const int win = wb % (a.nw * a.nw), wy = win / a.nw, wx = win - wy * a.nw;
-        if (wy * a.ws + n / a.ws < a.g && wx * a.ws + n % a.ws < a.g) continue;   // a real token: the GEMM wrote it
+        long long rest = id / (3 * hp);
+        const int head = int(rest % a.heads);
+        rest /= a.heads;
+        const int pt = int(rest % n_pad), b = int(rest / n_pad);
+        int y, x;
+        if (pt < pr * gp) { y = a.g + pt / gp; x = pt - (pt / gp) * gp; }
+        else { const int r2 = pt - pr * gp; y = r2 / pr; x = a.g + r2 - (r2 / pr) * pr; }
+        const int wy = y / a.ws, wx = x / a.ws;
+        const int n = (y - wy * a.ws) * a.ws + (x - wx * a.ws);
+        const int grp = ((b * a.nw + wy) * a.nw + wx) * a.heads + head;
         const int which = piece / hp, c0 = 8 * (piece - which * hp);
         const float* src = qkv_bias + which * a.dim + head * a.hd + c0;
         f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
@@ -800,7 +807,6 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
         // x = x + attn(norm1(x))                                         image_encoder.py:166-179
         POPE_TRY(layernorm(k.norm1_w, k.norm1_b));
         _Float16 *Qp = os.q, *Kp = os.k, *Vp = os.v;
-        const int G = a.B * a.nw * a.nw * a.heads;
         {
             // QKV projection written straight into the operand rows (window partition = os.map, q * scale * log2 e) ...
             GemmParams gq = {};
@@ -815,7 +821,7 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
             gq.sam_qscale = 1.0f / sqrtf(float(hd)) * L2E;
             POPE_TRY(pope_launch_planes16(gq, stream));
             if (a.nw * a.ws > a.g) {   // ... the rows of the edge windows' zero-padded tokens from the bias ...
-                const long long total = (long long)G * a.Nq * 3 * (hd / 8);
+                const long long total = (long long)a.B * (a.nw * a.ws * a.nw * a.ws - a.g * a.g) * a.heads * 3 * (hd / 8);
                 if (plain)
                     hipLaunchKernelGGL(sam_pad_tokens_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, k.qkv_b, Qp, Kp, Vp, a, flag);
                 else
