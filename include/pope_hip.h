@@ -285,9 +285,11 @@ int pope_fine_match_f32(const float* win0, const float* win1, int M, int Wn, int
  * `window` x `window` windows except in the blocks marked global, MLP ratio = hidden / dim, neck 1x1 conv ->
  * LayerNorm2d -> 3x3 conv -> LayerNorm2d).  image[B,3,img,img] fp32 (already normalised and padded by the caller,
  * sam.py preprocess) -> out[B,out_chans,g,g] fp32, g = img / patch.  head_dim = dim / heads must be 64 (ViT-B/L) or
- * 80 (ViT-H); dim % 128 == 0; out_chans % 256 == 0; patch % 8 == 0.  f16x3 arithmetic throughout (fp32 operands as
- * hi + lo f16 planes, three MFMAs per product, fp32 accumulate, fp32 softmax / LayerNorm / GELU / residual stream).
- * Weights: `*_wp` = weight planes (pope_split_planes_f32, scale 256) of the torch [out, in] matrices —
+ * 80 (ViT-H); dim % 128 == 0; out_chans % 256 == 0; patch % 8 == 0.  precision POPE_PREC_F16X3: fp32 operands as
+ * hi + lo f16 planes, three MFMAs per product; POPE_PREC_F16: plain f16 operands, one MFMA per product (see the field);
+ * fp32 accumulation, softmax, LayerNorm, GELU and residual stream in both.
+ * Weights: `*_wp` = weight planes (pope_split_planes_f32, scale 256; POPE_PREC_F16: f16 row-major, value * 256) of the
+ * torch [out, in] matrices —
  * patch_wp[dim, 3 patch^2] = proj.weight.reshape(dim, -1); neck0_wp[out_chans, dim]; neck2_wp[out_chans, 9 out_chans]
  * with the taps in (ky, kx, channel) order = weight.permute(0, 2, 3, 1).reshape(out_chans, -1).  pos[g*g, dim] or NULL.
  * rel_h / rel_w: the tables get_rel_pos returns (image_encoder.py:288-316), R[q][k][head_dim] fp32 with q, k < window
