@@ -1,11 +1,12 @@
 """Time the SAM image encoder (BASELINE config 5) on one GPU: `python scripts/sam_time.py [arch] [batch] [iters] [f16x3|f16]`
 (arch: vit_h | vit_l | vit_b).  Prints ms / image and algorithmic TFLOP/s (2 x MACs of the reference's own ops)."""
+import os
 import sys
 from functools import partial
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pope_amd import synth  # noqa: E402
 from pope_amd.sam_encoder import ImageEncoderViT  # noqa: E402
 
