@@ -122,6 +122,34 @@ def test_f16_precision_mode(hip_lib, golden_dir, name):
         m(x.cuda())
 
 
+@pytest.mark.parametrize("variant", ["no_abs_no_rel_all_global", "windows_only"])
+def test_constructor_variants_match_oracle(hip_lib, variant):
+    """The switches build_sam.py leaves on (image_encoder.py:34-39): without absolute / relative position terms and with
+    window_size = 0 (every block global), and with no global block at all — against the CPU oracle on seeded weights."""
+    from oracle import sam_encoder_ref
+    from pope_amd import synth
+    from pope_amd.sam_encoder import ImageEncoderViT
+    glob = variant == "no_abs_no_rel_all_global"
+    dim, depth, heads, img, window = 256, 2, 4, 224, (0 if glob else 14)
+    m = ImageEncoderViT(depth=depth, embed_dim=dim, img_size=img, mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+                        num_heads=heads, patch_size=16, qkv_bias=True, use_abs_pos=not glob, use_rel_pos=not glob,
+                        global_attn_indexes=[], window_size=window, out_chans=256)
+    sd = synth.synthetic_sam_encoder_state_dict(seed=3, dim=dim, depth=depth, heads=heads, grid=img // 16, window=window or img // 16,
+                                                global_idx=())
+    if glob:
+        sd = {k: v for k, v in sd.items() if k != "pos_embed" and "rel_pos" not in k}
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().cuda()
+    x = synth.synthetic_images(2, img, img, seed=5)
+    with torch.no_grad():
+        want = sam_encoder_ref.forward(sd, x, heads, window, ())
+    for prec, tol in (("f16x3", ATOL_OUT), ("f16", ATOL_F16)):
+        m.precision = prec
+        err = float((m(x.cuda()).cpu() - want).abs().max())
+        print(f"{variant} [{prec}]: max |out - oracle| = {err:.2e}")
+        assert err <= tol
+
+
 def test_contract_errors(hip_lib, golden_dir):
     from pope_amd.sam_encoder import ImageEncoderViT
     fx = np.load(os.path.join(golden_dir, "sam_hd64_224.npz"))
