@@ -1,8 +1,11 @@
-"""GPU: the drop-in LoFTR `Matcher` (src/matcher/matcher.py:29-79) end to end on the card — HIP coarse
-matcher inside PyTorch-ROCm CNN/transformer plumbing — against fixtures produced by the reference's own
-Matcher.  Index parity is bit-exact wherever the coarse features are the fixture's; end to end the features
-come from MIOpen/rocBLAS instead of the CPU kernels, so floats carry a tolerance and a match may only
-differ where the reference's own confidence is within that tolerance of the threshold or of a tie."""
+"""GPU: the drop-in LoFTR `Matcher` (src/matcher/matcher.py:29-79) end to end on the card — ResNet-FPN CNN, linear-attention
+transformers, coarse matcher and fine stage are all HIP calls (conv.hip, loftr.hip, match.hip, fine.hip) — against the
+fixtures produced by the reference's own Matcher (oracle/gen_golden.py) and against oracle/loftr_ref.py (the CPU
+restatement pinned to that reference at max-abs-diff 0.0), evaluated in fp32 and in fp64.
+
+Bounds (printed with the measured values): feature taps <= 2e-4 abs against the reference fixtures (|feat| <= 12);
+`mkpts1_f` <= 1e-3 px; the match list index-exact, ordering included, wherever the reference's confidence is clear of the
+threshold and of the runner-up in its row and column by 1e-3."""
 import copy
 import os
 
@@ -12,7 +15,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-FEAT_TOL = dict(rtol=2e-3, atol=2e-3)
+FEAT_ATOL = 2e-4      # feature maps / coarse features vs the reference fixture taps (values up to ~12)
+PX_ATOL = 1e-3        # mkpts1_f, pixels
+CLEAR = 1e-3          # a decision of the reference counts as clear when its confidence margin exceeds this
 
 
 @pytest.fixture(scope="module")
@@ -21,12 +26,23 @@ def dev(hip_lib):
     return torch.device("cuda:0")
 
 
-def build(thr, dev):
+@pytest.fixture(scope="module")
+def msd():
     from pope_amd import synth
-    from pope_amd.matcher import Matcher, default_cfg
+    return synth.synthetic_matcher_state_dict(seed=0)
+
+
+def cfg_with_thr(thr):
+    from pope_amd.matcher import default_cfg
     cfg = copy.deepcopy(default_cfg)
     cfg["match_coarse"]["thr"] = float(thr)
-    m = Matcher(cfg).eval()
+    return cfg
+
+
+def build(thr, dev):
+    from pope_amd import synth
+    from pope_amd.matcher import Matcher
+    m = Matcher(cfg_with_thr(thr)).eval()
     m.load_state_dict(synth.synthetic_matcher_state_dict(seed=0), strict=True)
     return m.to(dev)
 
@@ -39,6 +55,10 @@ def inputs(fx, dev):
         i1 = synth.synthetic_gray_pairs(n, *s1, seed=22)[0]
         i1[:, :, 32:224, :] = i0[:, :, :, 32:224]
     return i0.to(dev), i1.to(dev)
+
+
+def as64(sd):
+    return {k: v.double() for k, v in sd.items()}
 
 
 @pytest.mark.parametrize("name", ["loftr_256_lowthr", "loftr_192x256_vs_256x192"])
@@ -62,8 +82,30 @@ def test_coarse_stage_on_fixture_features_is_index_exact(dev, golden_dir, name):
     assert np.array_equal(conf.max(0)[1].cpu().numpy(), fx["conf_colarg"][0])
 
 
+def _clear_decisions(conf, thr, border, hw0, hw1):
+    """From the reference's confidence matrix [n, L, S] (oracle == fixture, bit for bit): the set of (b, i, j) the
+    reference accepts with every margin > CLEAR ("must"), and the set any implementation within CLEAR of the reference
+    may accept ("may").  coarse_matching.py:175-196."""
+    n, L, S = conf.shape
+    m = torch.ones(n, hw0[0], hw0[1], hw1[0], hw1[1], dtype=torch.bool)
+    bd = border
+    m[:, :bd] = m[:, -bd:] = False
+    m[:, :, :bd] = m[:, :, -bd:] = False
+    m[:, :, :, :bd] = m[:, :, :, -bd:] = False
+    m[:, :, :, :, :bd] = m[:, :, :, :, -bd:] = False
+    inside = m.reshape(n, L, S)
+    top2r = conf.topk(2, dim=2).values
+    top2c = conf.topk(2, dim=1).values
+    rmax, rsec = top2r[..., 0:1], top2r[..., 1:2]
+    cmax, csec = top2c[:, 0:1, :], top2c[:, 1:2, :]
+    must = inside & (conf > thr + CLEAR) & (conf == rmax) & (conf == cmax) & (rmax - rsec > CLEAR) & (cmax - csec > CLEAR)
+    may = inside & (conf > thr - CLEAR) & (conf >= rmax - CLEAR) & (conf >= cmax - CLEAR)
+    return must, may
+
+
 @pytest.mark.parametrize("name", ["loftr_256", "loftr_256_lowthr", "loftr_192x256_vs_256x192"])
-def test_matcher_end_to_end(dev, golden_dir, name):
+def test_matcher_end_to_end(dev, msd, golden_dir, name):
+    from oracle import loftr_ref
     fx = np.load(os.path.join(golden_dir, name + ".npz"))
     m = build(fx["thr"], dev)
     i0, i1 = inputs(fx, dev)
@@ -74,42 +116,64 @@ def test_matcher_end_to_end(dev, golden_dir, name):
         assert k in data, k
     assert tuple(data["hw0_c"]) == tuple(fx["hw0_c"]) and tuple(data["hw1_f"]) == tuple(fx["hw1_f"]) and data["W"] == 5
     thr = float(fx["thr"])
-    # matches whose reference confidence is clear of the threshold must be reproduced exactly
-    ref = {(int(b), int(i)): (int(j), float(c), k) for k, (b, i, j, c) in
-           enumerate(zip(fx["b_ids"], fx["i_ids"], fx["j_ids"], fx["mconf"]))}
-    got = {(int(b), int(i)): (int(j), float(c), k) for k, (b, i, j, c) in
-           enumerate(zip(data["b_ids"].cpu().numpy(), data["i_ids"].cpu().numpy(), data["j_ids"].cpu().numpy(),
-                         data["mconf"].cpu().numpy()))}
-    margin = 0.05 * thr + 1e-4
-    for key, (j, c, _) in ref.items():
-        if c > thr + margin:
-            assert key in got and got[key][0] == j, key
-    for key, (j, c, _) in got.items():
-        assert key in ref or c < thr + margin, key
-    common = sorted(set(ref) & set(got))
-    assert len(common) >= 0.9 * len(ref) > 0
-    ri, gi = [ref[k][2] for k in common], [got[k][2] for k in common]
-    np.testing.assert_allclose(data["mconf"].cpu().numpy()[gi], fx["mconf"][ri], rtol=3e-2, atol=1e-4)
+    # the reference's own confidence matrix: the oracle, tied to the fixture bit for bit
+    with torch.no_grad():
+        ref = loftr_ref.matcher_forward(msd, cfg_with_thr(thr), i0.cpu(), i1.cpu())
+    assert np.array_equal(ref["i_ids"].numpy(), fx["i_ids"]) and np.array_equal(ref["j_ids"].numpy(), fx["j_ids"])
+    assert np.array_equal(ref["conf_matrix"].max(2)[0].numpy(), fx["conf_rowmax"])
+    conf_err = float((data["conf_matrix"].cpu() - ref["conf_matrix"]).abs().max())
+    must, may = _clear_decisions(ref["conf_matrix"], thr, 2, tuple(fx["hw0_c"]), tuple(fx["hw1_c"]))
+    got_ids = torch.stack([data["b_ids"], data["i_ids"], data["j_ids"]], 1).cpu()
+    got_mask = torch.zeros_like(must)
+    got_mask[got_ids[:, 0], got_ids[:, 1], got_ids[:, 2]] = True
+    n_ref, n_must = len(fx["b_ids"]), int(must.sum())
+    assert bool((got_mask | ~must).all()), "a clear reference match is missing"
+    assert bool((may | ~got_mask).all()), "a match the reference clearly rejects was published"
+    identical = len(got_ids) == n_ref and np.array_equal(got_ids[:, 1].numpy(), fx["i_ids"]) and np.array_equal(got_ids[:, 2].numpy(), fx["j_ids"]) \
+        and np.array_equal(got_ids[:, 0].numpy(), fx["b_ids"])
+    print(f"{name}: {n_ref} reference matches, {n_must} clear by {CLEAR:g}; published {len(got_ids)}; list identical: {identical}; "
+          f"conf_matrix max err {conf_err:.2e}")
+    assert n_must >= 0.8 * n_ref > 0          # the fixture is not made of borderline cases
+    if n_must == n_ref:
+        assert identical
+    # floats on the matches common to both lists
+    ref_pos = {(int(b), int(i), int(j)): k for k, (b, i, j) in enumerate(zip(fx["b_ids"], fx["i_ids"], fx["j_ids"]))}
+    gi = [k for k, t in enumerate(map(tuple, got_ids.tolist())) if t in ref_pos]
+    ri = [ref_pos[tuple(got_ids[k].tolist())] for k in gi]
+    assert len(gi) >= n_must
+    e_conf = float(np.abs(data["mconf"].cpu().numpy()[gi] - fx["mconf"][ri]).max())
+    e_px = float(np.abs(data["mkpts1_f"].cpu().numpy()[gi] - fx["mkpts1_f"][ri]).max())
+    e_exp = float(np.abs(data["expec_f"].cpu().numpy()[gi] - fx["expec_f"][ri]).max())
+    print(f"{name}: mconf max err {e_conf:.2e}, mkpts1_f max err {e_px:.2e} px, expec_f max err {e_exp:.2e}")
+    assert e_conf <= 1e-3 and e_px <= PX_ATOL
+    # the spread column of expec_f is sqrt(E[g^2] - E[g]^2): for peaked windows the cancellation amplifies fp32 noise (in the
+    # reference's own arithmetic too), so it carries the looser bound
+    np.testing.assert_allclose(data["expec_f"].cpu().numpy()[gi][:, :2], fx["expec_f"][ri][:, :2], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(data["expec_f"].cpu().numpy()[gi][:, 2], fx["expec_f"][ri][:, 2], rtol=0, atol=2e-3)
     assert np.array_equal(data["mkpts0_c"].cpu().numpy()[gi], fx["mkpts0_c"][ri])
     assert np.array_equal(data["mkpts0_f"].cpu().numpy()[gi], fx["mkpts0_f"][ri])
-    np.testing.assert_allclose(data["mkpts1_f"].cpu().numpy()[gi], fx["mkpts1_f"][ri], rtol=0, atol=2e-2)   # pixels
-    np.testing.assert_allclose(data["expec_f"].cpu().numpy()[gi], fx["expec_f"][ri], rtol=0, atol=5e-3)
     # ordering: (b, i) ascending like torch.where (coarse_matching.py:193)
     order = data["b_ids"].cpu().numpy().astype(np.int64) * 10 ** 6 + data["i_ids"].cpu().numpy()
     assert np.all(np.diff(order) > 0)
 
 
-def test_only_att_fea_and_feature_parity(dev, golden_dir):
-    fx = np.load(os.path.join(golden_dir, "loftr_256_lowthr.npz"))
+@pytest.mark.parametrize("name", ["loftr_256_lowthr", "loftr_192x256_vs_256x192"])
+def test_only_att_fea_and_feature_parity(dev, golden_dir, name):
+    """Backbone maps and coarse-transformer features against the reference fixture's taps."""
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
     m = build(fx["thr"], dev)
     i0, i1 = inputs(fx, dev)
     f0, f1 = m({"image0": i0, "image1": i1}, only_att_fea=True)     # matcher.py:67-68
-    assert f0.shape == (2, 1024, 256)
-    np.testing.assert_allclose(f0[:, ::8].cpu().numpy(), fx["feat_c0"], **FEAT_TOL)
-    np.testing.assert_allclose(f1[:, ::8].cpu().numpy(), fx["feat_c1"], **FEAT_TOL)
-    bc, bf = m.backbone(torch.cat([i0, i1], 0))
-    np.testing.assert_allclose(bc[:1, :, ::2, ::2].cpu().numpy(), fx["backbone_c"], **FEAT_TOL)
-    np.testing.assert_allclose(bf[:1, ::4, ::8, ::8].cpu().numpy(), fx["backbone_f"], **FEAT_TOL)
+    n = int(fx["n"])
+    assert f0.shape == (n, int(np.prod(fx["hw0_c"])), 256)
+    errs = {"feat_c0": float(np.abs(f0[:, ::8].cpu().numpy() - fx["feat_c0"]).max()),
+            "feat_c1": float(np.abs(f1[:, ::8].cpu().numpy() - fx["feat_c1"]).max()),
+            "feat_c0_b0": float(np.abs(f0[0].cpu().numpy() - fx["feat_c0_b0"]).max())}
+    bc, bf = m.backbone(i0)
+    errs["backbone_c"] = float(np.abs(bc[:1, :, ::2, ::2].cpu().numpy() - fx["backbone_c"]).max())
+    errs["backbone_f"] = float(np.abs(bf[:1, ::4, ::8, ::8].cpu().numpy() - fx["backbone_f"]).max())
+    print(name, {k: f"{v:.2e}" for k, v in errs.items()}, f"bound {FEAT_ATOL:g}")
+    assert max(errs.values()) <= FEAT_ATOL, errs
 
 
 def test_graph_replay_is_bit_identical_to_eager_launches(dev, golden_dir):
@@ -164,46 +228,52 @@ def test_no_coarse_match_short_circuit(dev):
     assert data["conf_matrix"].shape == (1, 96, 96)
 
 
-# ---- the HIP LoFTR encoder layer (first slice) -----------------------------------------------------
+# ---- per-stage parity: each HIP stage against oracle/loftr_ref.py (pinned to the reference), in fp32 and in fp64 ------
 
-def _transformer(kind, dev, seed=0):
-    from pope_amd import synth
+def _transformer(kind, dev, msd):
     from pope_amd.loftr import LocalFeatureTransformer
     from pope_amd.matcher import default_cfg
     t = LocalFeatureTransformer(default_cfg[kind]).eval()
     prefix = "loftr_coarse." if kind == "coarse" else "loftr_fine."
-    sd = synth.synthetic_matcher_state_dict(seed=seed)
-    t.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, strict=True)
+    t.load_state_dict({k[len(prefix):]: v for k, v in msd.items() if k.startswith(prefix)}, strict=True)
     return t.to(dev)
+
+
+def _oracle_transformer(sd, kind, f0, f1):
+    from oracle import loftr_ref
+    from pope_amd.matcher import default_cfg
+    c = default_cfg[kind]
+    with torch.no_grad():
+        return loftr_ref.local_feature_transformer(sd, "loftr_" + kind, f0, f1, c["layer_names"], c["nhead"])
 
 
 @pytest.mark.parametrize("kind,n,L,S", [("coarse", 2, 1024, 1024), ("coarse", 3, 768, 1024), ("coarse", 1, 4800, 4800),
                                         ("fine", 153, 25, 25), ("fine", 1, 25, 25)])
-def test_hip_encoder_matches_fp64_restatement(dev, kind, n, L, S):
+def test_hip_encoder_matches_oracle(dev, msd, kind, n, L, S):
     """LocalFeatureTransformer on the HIP layer (f16x3 planes GEMMs + O(L) linear attention + fused LayerNorms) against
-    the same module evaluated in float64 on the CPU (transformer.py:85-106 semantics: 'cross' feeds the NEW feat0)."""
-    t = _transformer(kind, dev)
+    oracle/loftr_ref.py:local_feature_transformer (transformer.py:85-106: 'cross' feeds the NEW feat0) evaluated in
+    float64 (distance to the exact result) and in float32 (the reference's own arithmetic)."""
+    t = _transformer(kind, dev, msd)
     C = t.d_model
     g = torch.Generator().manual_seed(L + S + n)
     f0, f1 = torch.randn(n, L, C, generator=g), torch.randn(n, S, C, generator=g)
-    ref = copy.deepcopy(t).cpu().double()
-    ref.use_hip = False
+    w0, w1 = _oracle_transformer(as64(msd), kind, f0.double(), f1.double())
+    r0, r1 = _oracle_transformer(msd, kind, f0, f1)
     with torch.no_grad():
-        w0, w1 = ref(f0.double(), f1.double())
         g0, g1 = t(f0.to(dev), f1.to(dev))
-        t.use_hip = False
-        p0, p1 = t(f0.to(dev), f1.to(dev))     # the torch / rocBLAS plumbing this replaces
     e_hip = max(float((g0.cpu().double() - w0).abs().max()), float((g1.cpu().double() - w1).abs().max()))
-    e_torch = max(float((p0.cpu().double() - w0).abs().max()), float((p1.cpu().double() - w1).abs().max()))
+    e_ref = max(float((r0.double() - w0).abs().max()), float((r1.double() - w1).abs().max()))
+    e_vs_ref = max(float((g0.cpu() - r0).abs().max()), float((g1.cpu() - r1).abs().max()))
     scale = float(w0.abs().max())
-    print(f"{kind} n={n} L={L} S={S}: max err HIP {e_hip:.2e}, torch fp32 {e_torch:.2e}, |feat| max {scale:.2f}")
-    assert e_hip < 2e-4 * max(1.0, scale)
-    assert e_hip < 4 * e_torch + 2e-5        # fp32-equivalent: not worse than the fp32 library path it replaces
+    print(f"{kind} n={n} L={L} S={S}: max err vs fp64 oracle: HIP {e_hip:.2e}, fp32 oracle {e_ref:.2e}; HIP vs fp32 oracle "
+          f"{e_vs_ref:.2e}; |feat| max {scale:.2f}")
+    assert e_vs_ref <= FEAT_ATOL
+    assert e_hip < 4 * e_ref + 2e-5          # fp32-equivalent: as close to the exact result as the reference's fp32 chain
     assert g0.shape == (n, L, C) and g1.shape == (n, S, C) and bool(torch.isfinite(g0).all())
 
 
-def test_hip_encoder_is_deterministic_and_batch_invariant(dev):
-    t = _transformer("coarse", dev)
+def test_hip_encoder_is_deterministic_and_batch_invariant(dev, msd):
+    t = _transformer("coarse", dev, msd)
     g = torch.Generator().manual_seed(4)
     f0, f1 = torch.randn(3, 320, 256, generator=g).to(dev), torch.randn(3, 256, 256, generator=g).to(dev)
     with torch.no_grad():
@@ -215,60 +285,61 @@ def test_hip_encoder_is_deterministic_and_batch_invariant(dev):
     assert f0.data_ptr() != a0.data_ptr()      # inputs are not modified
 
 
-def test_hip_encoder_range_guard_falls_back(dev):
-    t = _transformer("coarse", dev)
+def test_hip_encoder_range_guard_reruns_in_fp32(dev, msd):
+    """An activation outside the f16x3 range: the device flag fires, the transformer is re-run without the range contract
+    (one warning) and the result is the reference's."""
+    t = _transformer("coarse", dev, msd)
     g = torch.Generator().manual_seed(5)
-    f0, f1 = torch.randn(1, 128, 256, generator=g).to(dev), torch.randn(1, 128, 256, generator=g).to(dev)
+    f0, f1 = torch.randn(1, 128, 256, generator=g), torch.randn(1, 128, 256, generator=g)
     f0[0, 7, 3] = 2.0e4                         # |x| * 8 >= 65504
     with torch.no_grad(), pytest.warns(UserWarning, match="LoFTR transformer"):
-        a0, a1 = t(f0, f1)
-    t.use_hip = False
-    with torch.no_grad():
-        b0, b1 = t(f0, f1)
-    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+        a0, a1 = t(f0.to(dev), f1.to(dev))
+    r0, r1 = _oracle_transformer(as64(msd), "coarse", f0.double(), f1.double())
+    for a, r in ((a0, r0), (a1, r1)):
+        assert bool(torch.isfinite(a).all())
+        err = float((a.cpu().double() - r).abs().max()) / max(1.0, float(r.abs().max()))
+        assert err < 1e-4, err
 
 
 # ---- the HIP ResNet-FPN (SURVEY.md §8 f-1, a-14): every convolution on the f16x3 planes GEMM ---------------------------
 
-def _backbone(dev, seed=0):
-    from pope_amd import synth
+def _backbone(dev, msd):
     from pope_amd.loftr import build_backbone
     from pope_amd.matcher import default_cfg
     b = build_backbone(default_cfg).eval()
-    sd = synth.synthetic_matcher_state_dict(seed=seed)
-    b.load_state_dict({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}, strict=True)
+    b.load_state_dict({k[len("backbone."):]: v for k, v in msd.items() if k.startswith("backbone.")}, strict=True)
     return b.to(dev)
 
 
 @pytest.mark.parametrize("n,H,W", [(2, 256, 256), (1, 64, 96), (3, 192, 256), (1, 16, 24)])
-def test_hip_backbone_matches_fp64_restatement(dev, n, H, W):
+def test_hip_backbone_matches_oracle(dev, msd, n, H, W):
     """ResNetFPN_8_2 (resnet_fpn.py:100-118) on the HIP path — implicit 3x3 convolutions over zero-bordered NHWC planes,
-    gathered stride-2 taps, fused BN / ReLU / LeakyReLU / shortcut epilogues, bilinear x2 + lateral add — against the same
-    module evaluated in float64 on the CPU, next to the MIOpen fp32 path it replaces."""
+    gathered stride-2 taps, fused BN / ReLU / LeakyReLU / shortcut epilogues, bilinear x2 + lateral add — against
+    oracle/loftr_ref.py:resnet_fpn_8_2 (separate conv and BatchNorm, the reference's op order) in fp32 and in fp64."""
+    from oracle import loftr_ref
     from pope_amd import synth
-    b = _backbone(dev)
+    b = _backbone(dev, msd)
     x = synth.synthetic_gray_pairs(n, H, W, seed=n + H)[0]
-    ref = copy.deepcopy(b).cpu().double()
-    ref.use_hip = False
     with torch.no_grad():
-        wc, wf = ref(x.double())
+        wc, wf = loftr_ref.resnet_fpn_8_2(as64(msd), x.double())
+        rc, rf = loftr_ref.resnet_fpn_8_2(msd, x)
         gc, gf = b(x.to(dev))
-        b.use_hip = False
-        pc, pf = b(x.to(dev))
     assert gc.shape == (n, 256, H // 8, W // 8) and gf.shape == (n, 128, H // 2, W // 2)
-    for name, g, p, w in (("coarse", gc, pc, wc), ("fine", gf, pf, wf)):
+    for name, g, r, w in (("coarse", gc, rc, wc), ("fine", gf, rf, wf)):
         e_hip = float((g.cpu().double() - w).abs().max())
-        e_torch = float((p.cpu().double() - w).abs().max())
+        e_ref = float((r.double() - w).abs().max())
+        e_vs_ref = float((g.cpu() - r).abs().max())
         scale = float(w.abs().max())
-        print(f"backbone {name} n={n} {H}x{W}: max err HIP {e_hip:.2e}, MIOpen fp32 {e_torch:.2e}, |feat| max {scale:.2f}")
-        assert e_hip < 1e-4 * max(1.0, scale)
-        assert e_hip < 4 * e_torch + 2e-5 * max(1.0, scale)
+        print(f"backbone {name} n={n} {H}x{W}: max err vs fp64 oracle: HIP {e_hip:.2e}, fp32 oracle {e_ref:.2e}; HIP vs fp32 "
+              f"oracle {e_vs_ref:.2e}; |feat| max {scale:.2f}")
+        assert e_vs_ref <= FEAT_ATOL
+        assert e_hip < 4 * e_ref + 2e-5 * max(1.0, scale)
         assert bool(torch.isfinite(g).all())
 
 
-def test_hip_backbone_is_deterministic_and_batch_invariant(dev):
+def test_hip_backbone_is_deterministic_and_batch_invariant(dev, msd):
     from pope_amd import synth
-    b = _backbone(dev)
+    b = _backbone(dev, msd)
     x = synth.synthetic_gray_pairs(3, 64, 96, seed=9)[0].to(dev)
     with torch.no_grad():
         a = b(x)
@@ -278,40 +349,37 @@ def test_hip_backbone_is_deterministic_and_batch_invariant(dev):
     assert torch.equal(a[0][1:2], d[0]) and torch.equal(a[1][1:2], d[1])
 
 
-def test_hip_backbone_range_guard_falls_back(dev):
+def test_hip_backbone_range_guard_reruns_in_fp32(dev, msd):
+    from oracle import loftr_ref
     from pope_amd import synth
-    b = _backbone(dev)
-    x = synth.synthetic_gray_pairs(1, 64, 64, seed=3)[0].to(dev)
+    b = _backbone(dev, msd)
+    x = synth.synthetic_gray_pairs(1, 64, 64, seed=3)[0]
     x[0, 0, 10, 10] = 1.0e4                     # |x| * 8 >= 65504: the stem gather raises the flag
     with torch.no_grad(), pytest.warns(UserWarning, match="LoFTR backbone"):
-        a = b(x)
-    b.use_hip = False
-    with torch.no_grad():
-        c = b(x)
-    # both are the torch / MIOpen form (not bit-reproducible from call to call: MIOpen picks its solver on first use)
-    assert bool(torch.isfinite(a[0]).all())
-    for u, v in zip(a, c):
-        assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max())
+        a = b(x.to(dev))
+        w = loftr_ref.resnet_fpn_8_2(as64(msd), x.double())
+    for u, v in zip(a, w):
+        assert bool(torch.isfinite(u).all())
+        assert float((u.cpu().double() - v).abs().max()) <= 1e-4 * float(v.abs().max())
 
 
 # ---- the HIP fine stage: window gather + down_proj / merge_feat, and the sub-pixel expectation ------
 
-def _fine_modules(dev):
-    from pope_amd import synth
+def _fine_modules(dev, msd):
     from pope_amd.loftr import FinePreprocess, FineMatching
     from pope_amd.matcher import default_cfg
     fp = FinePreprocess(default_cfg).eval()
-    sd = synth.synthetic_matcher_state_dict(seed=0)
-    fp.load_state_dict({k[len("fine_preprocess."):]: v for k, v in sd.items() if k.startswith("fine_preprocess.")}, strict=True)
+    fp.load_state_dict({k[len("fine_preprocess."):]: v for k, v in msd.items() if k.startswith("fine_preprocess.")}, strict=True)
     return fp.to(dev), FineMatching()
 
 
 @pytest.mark.parametrize("layout", ["nchw", "nhwc_view"])
 @pytest.mark.parametrize("M", [1, 37, 600])
-def test_hip_fine_preprocess_matches_torch_form(dev, layout, M):
-    """pope_fine_preprocess_f32 against the torch restatement of fine_preprocess.py:29-59 (itself pinned to the reference by
-    the Matcher fixtures): windows at random cells incl. the map's corners (zero padding), both memory layouts."""
-    fp, _ = _fine_modules(dev)
+def test_hip_fine_preprocess_matches_oracle(dev, msd, layout, M):
+    """pope_fine_preprocess_f32 against oracle/loftr_ref.py:fine_preprocess (the reference's unfold-then-index form,
+    fine_preprocess.py:29-59): windows at random cells incl. the map's corners (zero padding), both memory layouts."""
+    from oracle import loftr_ref
+    fp, _ = _fine_modules(dev, msd)
     g = torch.Generator().manual_seed(M)
     n, hc, wc, s = 2, 12, 16, 4
     hf, wf = hc * s, wc * s
@@ -328,33 +396,33 @@ def test_hip_fine_preprocess_matches_torch_form(dev, layout, M):
     data = {"hw0_f": (hf, wf), "hw0_c": (hc, wc), "hw1_c": (hc, wc), "b_ids": b.to(dev), "i_ids": i.to(dev), "j_ids": j.to(dev)}
     with torch.no_grad():
         g0, g1 = fp(f0, f1, c0, c1, dict(data))
-        fp.use_hip = False
-        w0, w1 = fp(f0, f1, c0, c1, dict(data))
-        r0, r1 = copy.deepcopy(fp).cpu().double()(f0.cpu().double(), f1.cpu().double(), c0.cpu().double(), c1.cpu().double(),
-                                                  {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in data.items()})
+        args = (f0.cpu().contiguous(), f1.cpu().contiguous(), c0.cpu(), c1.cpu())
+        r0, r1 = loftr_ref.fine_preprocess(msd, *args, b, i, j, 5, s)
+        w0, w1 = loftr_ref.fine_preprocess(as64(msd), *(a.double() for a in args), b, i, j, 5, s)
     assert g0.shape == (M, 25, 128) and g1.shape == (M, 25, 128)
-    e_hip = max(float((g0.cpu().double() - r0).abs().max()), float((g1.cpu().double() - r1).abs().max()))
-    e_torch = max(float((w0.cpu().double() - r0).abs().max()), float((w1.cpu().double() - r1).abs().max()))
-    print(f"fine preprocess M={M} {layout}: max err HIP {e_hip:.2e}, torch fp32 {e_torch:.2e}")
-    assert e_hip < 4 * e_torch + 2e-5
+    e_hip = max(float((g0.cpu().double() - w0).abs().max()), float((g1.cpu().double() - w1).abs().max()))
+    e_ref = max(float((r0.double() - w0).abs().max()), float((r1.double() - w1).abs().max()))
+    e_vs_ref = max(float((g0.cpu() - r0).abs().max()), float((g1.cpu() - r1).abs().max()))
+    print(f"fine preprocess M={M} {layout}: max err vs fp64 oracle: HIP {e_hip:.2e}, fp32 oracle {e_ref:.2e}; HIP vs fp32 oracle {e_vs_ref:.2e}")
+    assert e_vs_ref <= 1e-4 and e_hip < 4 * e_ref + 2e-5
 
 
 @pytest.mark.parametrize("M", [1, 5, 333])
-def test_hip_fine_matching_matches_torch_form(dev, M):
-    _, fm = _fine_modules(dev)
+def test_hip_fine_matching_matches_oracle(dev, msd, M):
+    """pope_fine_match_f32 against oracle/loftr_ref.py:fine_matching (fine_matching.py:15-74)."""
+    from oracle import loftr_ref
+    _, fm = _fine_modules(dev, msd)
     g = torch.Generator().manual_seed(100 + M)
-    w0, w1 = torch.randn(M, 25, 128, generator=g).to(dev), torch.randn(M, 25, 128, generator=g).to(dev)
+    w0, w1 = torch.randn(M, 25, 128, generator=g), torch.randn(M, 25, 128, generator=g)
     w1[:, 7] = w0[:, 12] * 1.5                        # a clear peak off the centre
-    mk = (torch.rand(M, 2, generator=g) * 200).to(dev)
-    base = {"hw0_i": (256, 256), "hw0_f": (128, 128), "mkpts0_c": mk.clone(), "mkpts1_c": mk.clone(), "mconf": torch.ones(M, device=dev),
-            "b_ids": torch.zeros(M, dtype=torch.long, device=dev)}
-    a, b = dict(base), dict(base)
-    fm(w0, w1, a)
-    fm.use_hip = False
-    fm(w0, w1, b)
-    torch.testing.assert_close(a["expec_f"][:, :2], b["expec_f"][:, :2], rtol=1e-5, atol=1e-5)
+    mk = torch.rand(M, 2, generator=g) * 200
+    a = {"hw0_i": (256, 256), "hw0_f": (128, 128), "mkpts0_c": mk.clone().to(dev), "mkpts1_c": mk.clone().to(dev),
+         "mconf": torch.ones(M, device=dev), "b_ids": torch.zeros(M, dtype=torch.long, device=dev)}
+    fm(w0.to(dev), w1.to(dev), a)
+    expec, mk0f, mk1f = loftr_ref.fine_matching(w0, w1, mk.clone(), mk.clone(), 2.0)
+    torch.testing.assert_close(a["expec_f"][:, :2].cpu(), expec[:, :2], rtol=1e-5, atol=1e-5)
     # the spread is sqrt(E[g^2] - E[g]^2) per axis (fine_matching.py:52-54): for a peaked heatmap the difference cancels
     # to fp32 noise (~1e-7) and its square root amplifies that to ~3e-4 — in the reference's own arithmetic too
-    torch.testing.assert_close(a["expec_f"][:, 2], b["expec_f"][:, 2], rtol=1e-4, atol=5e-4)
-    torch.testing.assert_close(a["mkpts1_f"], b["mkpts1_f"], rtol=1e-6, atol=1e-4)
-    assert torch.equal(a["mkpts0_f"], b["mkpts0_f"])
+    torch.testing.assert_close(a["expec_f"][:, 2].cpu(), expec[:, 2], rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(a["mkpts1_f"].cpu(), mk1f, rtol=1e-6, atol=1e-4)
+    assert torch.equal(a["mkpts0_f"].cpu(), mk0f)
