@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define POPE_ABI_VERSION 6
+#define POPE_ABI_VERSION 7
 
 enum {
     POPE_EPI_BIAS = 0,        /* C = A.W^T + bias                         nn.Linear                     */
@@ -348,6 +348,34 @@ int pope_crop_normalize_u8_f32(const unsigned char* img_hwc, int P, int Hin, int
 /* cv2.cvtColor(BGR2GRAY) (8-bit fixed point) followed by / 255. — eval_linemod_json.py:103-111:
  * bgr_hwc[P,H,W,3] uint8 -> out[P,1,H,W] fp32 in [0,1] (the Matcher's input). */
 int pope_gray_u8_f32(const unsigned char* bgr_hwc, int P, int H, int W, float* out, void* stream);
+
+/* ---- relative pose from the matches ----------------------------------------------------------- */
+
+/* estimate_pose for B pairs in one launch — src/utils/metrics.py:69-94 (call site eval_linemod_json.py:160): K-normalise
+ * both point sets (:72-75), threshold = thresh / mean(fx0, fy1, fx0, fy1) (:78), essential matrix by RANSAC over five-point
+ * minimal samples (what cv2.findEssentialMat(..., cv2.RANSAC) does: Sampson error <= threshold^2, a model is kept when it has
+ * MORE inliers than the best so far and at least five, budget log(1 - conf) / log(1 - w^5) re-evaluated after every round of
+ * 256 hypotheses, at most max_iters — OpenCV's default is 1000), then recoverPose for every returned E (:86-94): the
+ * (R, t) of the four decompositions with the most inliers in front of both cameras.  A pair with exactly five matches is
+ * the minimal problem itself: all of its solutions go through recoverPose.  All arithmetic fp64.
+ * Inputs are the dense matcher's compacted outputs as they lie in HBM: kpts0 / kpts1 [M, 2] fp32 pixel coordinates with
+ * the matches of pair b contiguous and pairs in order (mkpts0_c / mkpts1_c or mkpts0_f / mkpts1_f), counts [B] int32
+ * (DEVICE: matches per pair, sum <= M), K0 / K1 [B, 9] fp64 row-major intrinsics of image 0 / image 1 of each pair.
+ * Outputs: R [B, 9], t [B, 3] (unit norm), E [B, 9] fp64; inliers [M] bytes (RANSAC inlier AND in front of both cameras,
+ * the mask recoverPose leaves behind); info [B, 8] int32 = {n_inliers of the returned pose — 0 means `None` (fewer than five
+ * matches, no model with five inliers, or no point in front of both cameras) —, RANSAC inliers, hypotheses tried, rounds,
+ * winning hypothesis, winning root, matches of the pair, status (-1: counts exceed M)}.
+ * The minimal samples of hypothesis h come from a counter-based hash of (seed, h): results do not depend on the batch a
+ * pair rides in.  cv2's own random stream is not reproducible without cv2 (absent here): parity with OpenCV is unpinned,
+ * the checker is oracle/pose_ref.py (same algorithm, same samples, numpy fp64). */
+size_t pope_estimate_pose_workspace_bytes(long long M);
+int pope_estimate_pose_f64(const float* kpts0, const float* kpts1, const int* counts, const double* K0, const double* K1,
+                           int B, long long M, double thresh, double conf, int max_iters, unsigned long long seed,
+                           double* R, double* t, double* E, unsigned char* inliers, int* info,
+                           void* workspace, size_t workspace_bytes, void* stream);
+/* The minimal solver alone (parity tests): S problems of five correspondences in normalised coordinates,
+ * x0 / x1 [S, 5, 2] fp64 -> E_out [S, 10, 9] (unit Frobenius norm, ascending root order, zero filled), n_out [S]. */
+int pope_five_point_f64(const double* x0, const double* x1, int S, double* E_out, int* n_out, void* stream);
 
 /* ---- host-side helper ------------------------------------------------------------------------ */
 

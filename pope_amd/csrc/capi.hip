@@ -684,3 +684,21 @@ int pope_streaming_top3_host(const float* scores, int P, float* slot_scores, lon
 }
 
 }  // extern "C"
+
+size_t pope_estimate_pose_workspace_bytes(long long M) { return pope_pose_workspace(M); }
+
+int pope_estimate_pose_f64(const float* kpts0, const float* kpts1, const int* counts, const double* K0, const double* K1, int B,
+                           long long M, double thresh, double conf, int max_iters, unsigned long long seed, double* R, double* t,
+                           double* E, unsigned char* inliers, int* info, void* workspace, size_t workspace_bytes, void* stream) {
+    StreamDevice on_device(stream);
+    PoseParams q = {};
+    q.kpts0 = kpts0; q.kpts1 = kpts1; q.counts = counts; q.K0 = K0; q.K1 = K1; q.B = B; q.M = M;
+    q.thresh = thresh; q.conf = conf; q.max_iters = max_iters; q.seed = seed;
+    q.R = R; q.t = t; q.E = E; q.inliers = inliers; q.info = info;
+    return pope_launch_estimate_pose(q, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int pope_five_point_f64(const double* x0, const double* x1, int S, double* E_out, int* n_out, void* stream) {
+    StreamDevice on_device(stream);
+    return pope_launch_five_point(x0, x1, S, E_out, n_out, static_cast<hipStream_t>(stream));
+}

@@ -267,3 +267,21 @@ struct SamEncParams {
 };
 size_t pope_sam_encoder_workspace(const SamEncParams& q);
 int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream);
+
+// Batched relative pose (pose.hip; src/utils/metrics.py:69-94): one workgroup per pair
+struct PoseParams {
+    const float* kpts0; const float* kpts1;   // [M, 2] fp32 pixel coordinates, the matches of pair b contiguous, pairs in order
+    const int* counts;                        // [B] matches per pair (device; the matcher's counts)
+    const double* K0; const double* K1;       // [B, 9] intrinsics, row-major
+    int B; long long M;                       // M = rows of kpts0 / kpts1 (capacity; sum(counts) <= M)
+    double thresh, conf;                      // pixels; RANSAC confidence
+    int max_iters;
+    unsigned long long seed;
+    double* R; double* t; double* E;          // [B, 9], [B, 3], [B, 9]
+    unsigned char* inliers;                   // [M]
+    int* info;                                // [B, 8]: n_good (0 = None), RANSAC inliers, hypotheses, rounds, best hypothesis, best root, N, status
+    void* xn; unsigned char* mask_ws; unsigned char* cheir_ws;   // filled in by the launcher from the workspace
+};
+size_t pope_pose_workspace(long long M);
+int pope_launch_estimate_pose(PoseParams q, void* ws, size_t ws_bytes, hipStream_t stream);
+int pope_launch_five_point(const double* x0, const double* x1, int S, double* E_out, int* n_out, hipStream_t stream);

@@ -258,3 +258,34 @@ def synthetic_driver_case(n_proposals=8, seed=31):
                          + noise_gray * torch.randn(gray_ref[0].shape, generator=g)).clamp_(0, 1)
     crop_tensors[3] = crop_tensors[2]
     return ref_tensor, crop_tensors, gray_ref, gray_crops
+
+
+def synthetic_pose_scene(n, seed, outlier=0.3, noise=0.0, K0=None, K1=None):
+    """A planted two-view scene for the pose solver: n 3-D points in front of both cameras, a random
+    rotation of 5-30 degrees and a unit-direction translation of length 0.5, projected with K0 / K1 (defaults: the LINEMOD
+    camera and a 256x256 crop camera, the two intrinsics eval_linemod_json.py:160 passes), Gaussian pixel noise, and a
+    fraction `outlier` of the second image's points replaced by uniform clutter.
+    Returns numpy (kpts0 [n,2] f32, kpts1 [n,2] f32, K0, K1, R [3,3], t [3], planted_inlier [n] bool)."""
+    import numpy as np
+    g = np.random.default_rng(seed)
+    axis = g.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    ang = np.deg2rad(g.uniform(5, 30))
+    Kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+    t = g.normal(size=3)
+    t *= 0.5 / np.linalg.norm(t)
+    X = np.stack([g.uniform(-1, 1, n), g.uniform(-1, 1, n), g.uniform(3, 6, n)], 1)
+    K0 = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1.0]]) if K0 is None else np.asarray(K0, np.float64)
+    K1 = np.array([[600.0, 0, 128.0], [0, 610.0, 120.0], [0, 0, 1.0]]) if K1 is None else np.asarray(K1, np.float64)
+    p0 = (X / X[:, 2:]) @ K0.T
+    X1 = X @ R.T + t
+    p1 = (X1 / X1[:, 2:]) @ K1.T
+    k0 = p0[:, :2] + g.normal(size=(n, 2)) * noise
+    k1 = p1[:, :2] + g.normal(size=(n, 2)) * noise
+    n_out = int(outlier * n)
+    bad = g.permutation(n)[:n_out]
+    k1[bad] = np.stack([g.uniform(0, 256, n_out), g.uniform(0, 256, n_out)], 1)
+    inl = np.ones(n, bool)
+    inl[bad] = False
+    return k0.astype(np.float32), k1.astype(np.float32), K0, K1, R, t, inl

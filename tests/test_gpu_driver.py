@@ -43,7 +43,7 @@ def test_driver_step_matches_reference_loop(dev, models, golden_dir):
             e_conf = float(np.abs(got_c - ref_c).max()) if len(ref_c) else 0.0
             e_px = float(np.abs(out["mkpts1"][s] - fx[f"mkpts1_{s}"]).max()) if len(ref_c) else 0.0
             print(f"slot {s}: {len(ref_c)} matches, mconf max err {e_conf:.2e}, mkpts1 max err {e_px:.2e} px")
-            assert e_conf <= 1e-3 and e_px <= 1e-3
+            assert e_conf <= 2e-4 and e_px <= 5e-4
             assert np.array_equal(out["mkpts0"][s], fx[f"mkpts0_{s}"])
         near = int((np.abs(ref_c - 0.9) < 1e-3).sum())    # matching_score counts mconf > 0.9
         assert abs(int(out["matching_score"][s]) - int(fx["matching_score"][s])) <= near
