@@ -349,6 +349,18 @@ int pope_crop_normalize_u8_f32(const unsigned char* img_hwc, int P, int Hin, int
  * bgr_hwc[P,H,W,3] uint8 -> out[P,1,H,W] fp32 in [0,1] (the Matcher's input). */
 int pope_gray_u8_f32(const unsigned char* bgr_hwc, int P, int H, int W, float* out, void* stream);
 
+/* Proposal crops — get_image_crop_resize (utils/data_utils.py:239-255 = cv2.warpAffine(image, M, (w, h), INTER_LINEAR), border
+ * constant 0) as the drivers use it twice per SAM proposal (eval_linemod_json.py:83-90: crop at the expanded box's own size,
+ * an integer translation, then a uniform resize of that crop to 256 x 256), for P proposals of one frame in one launch.
+ * img_hwc[H, W, C] uint8 (C <= 4); minv[P, 6] fp64 (DEVICE): the INVERSE 2 x 3 map of each output (destination pixel ->
+ * source position in window coordinates; what cv::warpAffine derives from the forward matrix); win[P, 4] int32 (DEVICE) =
+ * (x0, y0, w, h): the source of output p is the w x h window of the frame at (x0, y0), everything outside the window or the
+ * frame reads 0 — i.e. the reference's intermediate zero-padded crop, never materialised; (0, 0, W, H) warps the frame itself.
+ * out[P, oh, ow, C] uint8.  Arithmetic: OpenCV's 8-bit bilinear convention (1/32 px positions, integer weights summing to
+ * 1024, round to nearest) — restated, unpinned against cv2 (absent); integer translations are exact copies. */
+int pope_crop_warp_u8(const unsigned char* img_hwc, int H, int W, int C, const double* minv, const int* win, int P,
+                      int oh, int ow, unsigned char* out, void* stream);
+
 /* ---- relative pose from the matches ----------------------------------------------------------- */
 
 /* estimate_pose for B pairs in one launch — src/utils/metrics.py:69-94 (call site eval_linemod_json.py:160): K-normalise

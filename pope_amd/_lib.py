@@ -114,6 +114,8 @@ PROTOTYPES = {
                                + [C.c_int] * 7 + [c_float_p, c_float_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pope_crop_normalize_u8_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [c_float_p, c_float_p, C.c_void_p, C.c_void_p]),
     "pope_gray_u8_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pope_crop_warp_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p]),
     "pope_estimate_pose_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "pope_estimate_pose_f64": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_longlong, C.c_double, C.c_double, C.c_int, C.c_ulonglong]
                                + [C.c_void_p] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -667,6 +667,12 @@ int pope_gray_u8_f32(const unsigned char* bgr_hwc, int P, int H, int W, float* o
     return pope_launch_gray(bgr_hwc, size_t(P) * H * W, out, static_cast<hipStream_t>(stream));
 }
 
+int pope_crop_warp_u8(const unsigned char* img_hwc, int H, int W, int C, const double* minv, const int* win, int P, int oh, int ow,
+                      unsigned char* out, void* stream) {
+    StreamDevice on_device(stream);
+    return pope_launch_crop_warp(img_hwc, H, W, C, minv, win, P, oh, ow, out, static_cast<hipStream_t>(stream));
+}
+
 int pope_streaming_top3_host(const float* scores, int P, float* slot_scores, long long* slot_index) {
     if (!scores || !slot_scores || !slot_index || P < 0) return POPE_ERR_ARG;
     for (int k = 0; k < 3; ++k) { slot_scores[k] = 0.f; slot_index[k] = -1; }

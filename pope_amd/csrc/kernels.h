@@ -185,6 +185,8 @@ struct PreprocParams {
 };
 int pope_launch_preprocess(const PreprocParams& p, hipStream_t stream);
 int pope_launch_gray(const unsigned char* bgr, size_t npix, float* out, hipStream_t stream);
+int pope_launch_crop_warp(const unsigned char* img, int H, int W, int C, const double* minv, const int* win, int P, int oh, int ow,
+                          unsigned char* out, hipStream_t stream);
 int pope_launch_crop_norm(const unsigned char* img, int P, int Hin, int Win, int top, int left, int ch, int cw, const float* mean,
                           const float* std, float* out, hipStream_t stream);
 

@@ -112,6 +112,44 @@ __global__ __launch_bounds__(256) void crop_norm_kernel(const unsigned char* __r
     }
 }
 
+
+// cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT 0) of uint8 images for P destination images at once — the drivers' proposal
+// crops (utils/data_utils.py:239-255 called twice, eval_linemod_json.py:83-90).  minv[p][6] = the INVERSE map (destination
+// pixel -> source position, what cv::warpAffine derives from the forward matrix) in fp64; evaluated per destination pixel
+// the way OpenCV's 8-bit path does: 10-bit fixed point with a 1/64 px rounding offset, truncated to 1/32 px, the four
+// neighbours blended with integer weights (32 - fx)(32 - fy) ... fx fy and rounded to nearest.  win[p] = (x0, y0, w, h):
+// the source of image p is the w x h window of `img` whose top-left corner is (x0, y0) — pixels outside the window or
+// outside `img` read as 0, which is exactly the intermediate zero-padded crop of the reference's first (integer
+// translation) step, so the two warps of a proposal are ONE gather from the frame.
+__global__ __launch_bounds__(256) void crop_warp_kernel(const unsigned char* __restrict__ img, int H, int W, int C,
+                                                        const double* __restrict__ minv, const int* __restrict__ win, int P, int oh,
+                                                        int ow, unsigned char* __restrict__ out) {
+    const size_t total = size_t(P) * oh * ow;
+    for (size_t id = size_t(blockIdx.x) * 256 + threadIdx.x; id < total; id += size_t(gridDim.x) * 256) {
+        const int x = int(id % ow), y = int((id / ow) % oh), p = int(id / (size_t(ow) * oh));
+        const double* m = minv + 6 * p;
+        const int x0 = win[4 * p], y0 = win[4 * p + 1], ww = win[4 * p + 2], wh = win[4 * p + 3];
+        // saturate_cast<int>(double) rounds to nearest even (rint)
+        const long long adelta = (long long)rint(m[0] * x * 1024.0), bdelta = (long long)rint(m[3] * x * 1024.0);
+        const long long X0 = (long long)rint((m[1] * y + m[2]) * 1024.0) + 16, Y0 = (long long)rint((m[4] * y + m[5]) * 1024.0) + 16;
+        const long long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+        const long long sx = X >> 5, sy = Y >> 5;
+        const int fx = int(X & 31), fy = int(Y & 31);
+        const int w00 = (32 - fx) * (32 - fy), w01 = fx * (32 - fy), w10 = (32 - fx) * fy, w11 = fx * fy;
+        const bool okx0 = sx >= 0 && sx < ww && sx + x0 >= 0 && sx + x0 < W, okx1 = sx + 1 >= 0 && sx + 1 < ww && sx + 1 + x0 >= 0 && sx + 1 + x0 < W;
+        const bool oky0 = sy >= 0 && sy < wh && sy + y0 >= 0 && sy + y0 < H, oky1 = sy + 1 >= 0 && sy + 1 < wh && sy + 1 + y0 >= 0 && sy + 1 + y0 < H;
+        const unsigned char* r0 = img + (size_t(oky0 ? sy + y0 : 0) * W) * C;
+        const unsigned char* r1 = img + (size_t(oky1 ? sy + 1 + y0 : 0) * W) * C;
+        const size_t c0 = size_t(okx0 ? sx + x0 : 0) * C, c1 = size_t(okx1 ? sx + 1 + x0 : 0) * C;
+        unsigned char* o = out + id * C;
+        for (int c = 0; c < C; ++c) {
+            const int p00 = (oky0 && okx0) ? r0[c0 + c] : 0, p01 = (oky0 && okx1) ? r0[c1 + c] : 0;
+            const int p10 = (oky1 && okx0) ? r1[c0 + c] : 0, p11 = (oky1 && okx1) ? r1[c1 + c] : 0;
+            o[c] = (unsigned char)((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + 512) >> 10);
+        }
+    }
+}
+
 inline unsigned grid_for(size_t n) { return unsigned(n / 256 + 1 < 16384 ? n / 256 + 1 : 16384); }
 
 }  // namespace
@@ -141,5 +179,12 @@ int pope_launch_crop_norm(const unsigned char* img, int P, int Hin, int Win, int
 int pope_launch_gray(const unsigned char* bgr, size_t npix, float* out, hipStream_t stream) {
     if (!bgr || !out || !npix) return POPE_ERR_ARG;
     hipLaunchKernelGGL(gray_kernel, dim3(grid_for(npix)), dim3(256), 0, stream, bgr, npix, out);
+    return pope_check_launch();
+}
+
+int pope_launch_crop_warp(const unsigned char* img, int H, int W, int C, const double* minv, const int* win, int P, int oh, int ow,
+                          unsigned char* out, hipStream_t stream) {
+    if (!img || !minv || !win || !out || H <= 0 || W <= 0 || C <= 0 || C > 4 || P <= 0 || oh <= 0 || ow <= 0) return POPE_ERR_ARG;
+    hipLaunchKernelGGL(crop_warp_kernel, dim3(grid_for(size_t(P) * oh * ow)), dim3(256), 0, stream, img, H, W, C, minv, win, P, oh, ow, out);
     return pope_check_launch();
 }
