@@ -163,6 +163,10 @@ def main():
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the short strict-fp32 leg of the N = 1 run")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the short BASELINE config 5 leg (DINOv2 ViT-L/14 and the SAM ViT-H image encoder) of the N = 1 run")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the LoFTR Matcher / driver-step / pose legs of the N = 1 run (bench_legs.py)")
+    ap.add_argument("--only", choices=["loftr_matcher", "driver_step", "pose"], default=None,
+                    help="profiling only: run just this leg (no headline line; prints the leg's JSON)")
     ap.add_argument("--no-verify", action="store_true",
                     help="profiling only: skip the self-check (its batch-1 launches would enter rocprof's per-kernel averages); "
                          "the line then carries \"verified\": null")
@@ -198,6 +202,16 @@ def main():
     from pope_amd import synth
     from pope_amd.dinov2_utils import load_dinov2_model
     from pope_amd.pipeline import PairPipeline, gather_counts, load_pair_list, shard_range, walk_pair_list
+
+    if args.only in ("loftr_matcher", "driver_step"):   # profiling passes of the secondary legs (scripts/profile_round.sh)
+        import bench_legs
+        vit, matcher = bench_legs.build_models(device)
+        if args.only == "loftr_matcher":
+            leg = {f"pairs_{n}": bench_legs.loftr_matcher_leg(matcher, device, n, cpu_baseline=False) for n in (3, 24)}
+        else:
+            leg = bench_legs.driver_step_leg(vit, matcher, device, cpu_baseline=False)
+        print(json.dumps({args.only: leg}))
+        return
 
     model = load_dinov2_model(state_dict=synth.synthetic_state_dict(seed=0)).to(device)
     match_precision = "f16x3" if args.precision == "f16" else args.precision
@@ -315,6 +329,7 @@ def main():
                                            if linemod else " (BASELINE config 3)"),
                    "pairs_per_gpu_per_step": (hi - lo) if linemod else args.pairs, "vit_chunk_images": args.chunk,
                    "weights": "seeded synthetic, reference state-dict layout",
+                   "want_conf": pipe.want_conf,   # False: match lists only — conf_matrix [n, L, S] (1.2 GB per step) is not published
                    "parallelism": f"pairs sharded over {world} GPU(s); RCCL all_gather of match counts"},
         "gflop_per_pair": round(flops_per_pair() / 1e9, 3),
         "achieved_tflops_whole_step": round(value * flops_per_pair() / 1e12 / world, 2),
@@ -348,6 +363,48 @@ def main():
     if rank == 0 and world == 1 and not linemod and not args.no_config5:
         torch.cuda.empty_cache()
         result["config5"] = config5_leg(device)
+    if rank == 0 and world == 1 and not linemod and (not args.no_legs or args.only == "pose"):
+        import bench_legs
+        cpu = not args.no_cpu_baseline
+        torch.cuda.empty_cache()
+        try:
+            result["pose"] = bench_legs.pose_leg(pipe, img0, img1, device, cpu_baseline=cpu)
+        except Exception as e:  # noqa: BLE001 — reported in place, the headline line stands
+            result["pose"] = {"error": f"{type(e).__name__}: {e}"}
+        if args.only is None:
+            try:   # the same step publishing conf_matrix [n, L, S] like the reference's CoarseMatching always does (coarse_matching.py:145)
+                pipe.want_conf = True
+                o2 = pipe(img0, img1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    o2 = pipe(img0, img1)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 2
+                k = args.pairs // 2
+                from pope_amd.matcher import dense_match
+                one = dense_match(o2["feat0"][k:k + 1], o2["feat1"][k:k + 1], (H_IMG // PATCH, W_IMG // PATCH), (H_IMG // PATCH, W_IMG // PATCH),
+                                  (H_IMG, W_IMG), precision=match_precision)
+                result["with_conf_matrix"] = {"value": round(args.pairs / dt, 2), "unit": "image-pairs/s", "ms_per_step": round(dt * 1e3, 3),
+                                              "conf_matrix_bytes_per_step": int(o2["conf_matrix"].numel()) * 4,
+                                              "verified": bool(torch.equal(o2["conf_matrix"][k], one["conf_matrix"][0])
+                                                               and torch.equal(o2["i_ids"][o2["b_ids"] == k], one["i_ids"])),
+                                              "note": "want_conf=True: the matcher also publishes conf_matrix; pair %d's matrix bit-equal to its batch-1 call" % k}
+                del o2, one
+            except Exception as e:  # noqa: BLE001
+                result["with_conf_matrix"] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                pipe.want_conf = False
+                torch.cuda.empty_cache()
+            try:
+                vit, matcher = bench_legs.build_models(device)
+                result["loftr_matcher"] = {"pairs_3": bench_legs.loftr_matcher_leg(matcher, device, 3, cpu_baseline=cpu),
+                                           "pairs_24": bench_legs.loftr_matcher_leg(matcher, device, 24)}
+                result["driver_step"] = bench_legs.driver_step_leg(vit, matcher, device, cpu_baseline=cpu)
+                del vit, matcher
+            except Exception as e:  # noqa: BLE001
+                result["loftr_matcher"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N = 1 only (the other ranks would idle)
         result["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
     if world > 1:
@@ -425,7 +482,9 @@ def roofline_entry(dominant, dom, peak_tflops, mfma_factor, chunk, pmc=True):
         "launches_timed": dom["launches"],
         "note": "algorithmic FLOPs / HIP-event duration of every launch of this kernel inside the timed "
                 "region (events on the launch stream); peak = dense MFMA peak of the MFMA dtype "
-                "(MI355X_MICROARCH.md); f16x3 executes 3 MFMA FLOPs per algorithmic FLOP",
+                "(MI355X_MICROARCH.md); f16x3 executes 3 MFMA FLOPs per algorithmic FLOP; `traffic` = HBM bytes per "
+                "launch from the committed rocprofv3 --pmc pass (profiles/pmc_traffic.json <- profiles/r02/pmc_summary.txt), "
+                "not measured in this run",
     }
 
 

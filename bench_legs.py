@@ -1,0 +1,257 @@
+"""Secondary legs of bench.py (N = 1 only; never part of `value`): the workloads the reference's drivers actually run
+around the headline path, each timed on synthetic data resident in HBM, self-checked against its own unbatched calls and
+reported next to a bounded CPU run of the oracle:
+
+  loftr_matcher   the drop-in LoFTR `Matcher` (src/matcher/matcher.py:29-79) on 3 pairs of 256x256 (what one query of
+                  eval_linemod_json.py:108-125 needs) and on 24 pairs (eight queries batched by the caller);
+  driver_step     one query of the drivers' loop (eval_linemod_json.py:62-127): reference crop + 8 proposal crops ->
+                  preprocessing -> DINOv2 CLS vote -> one 3-pair LoFTR call (`locate_and_match_u8`), and the same from the
+                  raw frame + proposal boxes through to the pose (`locate_match_pose_u8`: crops, K, RANSAC included);
+  pose            `estimate_pose` (src/utils/metrics.py:69-94) for the 128 pairs of the headline step straight from the
+                  matcher's device buffers, and the extract + match + pose rate.
+
+The oracle (oracle/) is imported here for the `cpu_baseline` entries only, after the timed regions.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+PEAK_F16_MFMA_TFLOPS = 2500.0
+
+
+def loftr_cnn_flops(H, W):
+    """Algorithmic FLOPs (2 * MAC) of ResNetFPN_8_2 on one H x W gray image (resnet_fpn.py:43-118; dims 128 / 196 / 256)."""
+    p2, p4, p8 = (H // 2) * (W // 2), (H // 4) * (W // 4), (H // 8) * (W // 8)
+    macs = p2 * 49 * 128                                   # 7x7 stem
+    macs += p2 * 4 * 9 * 128 * 128                         # layer1: four 3x3
+    macs += p4 * (9 * 128 * 196 + 3 * 9 * 196 * 196 + 128 * 196)      # layer2 (first conv stride 2, 1x1 shortcut)
+    macs += p8 * (9 * 196 * 256 + 3 * 9 * 256 * 256 + 196 * 256)      # layer3
+    macs += p8 * 256 * 256 + p4 * 196 * 256 + p4 * 9 * (256 * 256 + 256 * 196)       # layer3_outconv, layer2_outconv(2)
+    macs += p2 * 128 * 196 + p2 * 9 * (196 * 196 + 196 * 128)                         # layer1_outconv(2)
+    return 2 * macs
+
+
+def _events_ms(fn, iters):
+    """Mean duration of fn() over `iters` back-to-back calls by HIP events on the launch stream (torch's current stream is
+    the stream every pope_amd call launches on)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters, out
+
+
+def _wall_ms(fn, iters):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / iters, out
+
+
+def _cores():
+    return min(len(os.sched_getaffinity(0)), 16)
+
+
+def build_models(device):
+    from pope_amd import synth
+    from pope_amd.dinov2_utils import load_dinov2_model
+    from pope_amd.matcher import Matcher, default_cfg
+    matcher = Matcher(default_cfg).eval()
+    matcher.load_state_dict(synth.synthetic_matcher_state_dict(seed=0), strict=True)
+    vit = load_dinov2_model(state_dict=synth.synthetic_state_dict(seed=0)).to(device)
+    return vit, matcher.to(device)
+
+
+MATCH_KEYS = ("i_ids", "j_ids", "mconf", "mkpts0_f", "mkpts1_f", "expec_f")
+
+
+def loftr_matcher_leg(matcher, device, n_pairs, iters=10, cpu_baseline=False):
+    from pope_amd import synth
+    i0, i1 = (t.to(device) for t in synth.synthetic_gray_pairs(n_pairs, 256, 256, seed=21))
+
+    def call():
+        d = {"image0": i0, "image1": i1}
+        matcher(d)
+        return d
+
+    for _ in range(3):
+        call()
+    ms, d = _wall_ms(call, iters)      # the call synchronises itself (match-count readback), as the reference's does
+    both = torch.cat([i0, i1], 0)
+    cnn_ms, _ = _events_ms(lambda: matcher.backbone(both), iters)
+    fc = matcher.backbone(both)[0]
+    t0 = matcher.pos_encoding(fc[:n_pairs]).flatten(2).transpose(1, 2).contiguous()
+    t1 = matcher.pos_encoding(fc[n_pairs:]).flatten(2).transpose(1, 2).contiguous()
+    xf_ms, _ = _events_ms(lambda: matcher.loftr_coarse(t0, t1), iters)
+    # self-check: pairs of the batch alone through the same module
+    bad = []
+    for k in sorted({0, n_pairs // 2, n_pairs - 1}):
+        one = {"image0": i0[k:k + 1], "image1": i1[k:k + 1]}
+        matcher(one)
+        sel = d["b_ids"] == k
+        for key in MATCH_KEYS:
+            if not torch.equal(d[key][sel], one[key]):
+                bad.append(f"pair {k}: {key} differs from the batch-1 call")
+        if not torch.equal(d["conf_matrix"][k], one["conf_matrix"][0]):
+            bad.append(f"pair {k}: conf_matrix differs from the batch-1 call")
+    fl = 2 * n_pairs * loftr_cnn_flops(256, 256)
+    tf = fl / cnn_ms / 1e9
+    out = {"value": round(n_pairs * 1e3 / ms, 1), "unit": "LoFTR pairs/s", "pairs": n_pairs, "image": [256, 256], "ms_per_call": round(ms, 3),
+           "matches": int(len(d["b_ids"])), "verified": not bad,
+           "stages_ms": {"resnet_fpn": round(cnn_ms, 3), "coarse_transformer_8_layers": round(xf_ms, 3),
+                         "coarse_match_fine_stage_and_host": round(ms - cnn_ms - xf_ms, 3)},
+           "roofline": {"kernel": "ResNetFPN_8_2 forward (22 convolutions on gemm_planes16_kernel<EPI_CONV>; one C call)", "bound": "mfma",
+                        "achieved": round(tf, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4),
+                        "frac_of_executed_mfma_flops": round(3 * tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
+                        "flops_per_launch": fl, "avg_ms_per_launch": round(cnn_ms, 4), "launches_timed": iters,
+                        "note": f"{2 * n_pairs} images of 256x256 per call, {loftr_cnn_flops(256, 256) / 1e9:.2f} GFLOP each (closed form of "
+                                "resnet_fpn.py:43-118); HIP events around the C call on the launch stream; f16x3 arithmetic"}}
+    if bad:
+        out["verify_failures"] = bad[:6]
+    if cpu_baseline:
+        from oracle import loftr_ref
+        from pope_amd.matcher import default_cfg
+        torch.set_num_threads(_cores())
+        sd = synth.synthetic_matcher_state_dict(seed=0)
+        c0, c1 = i0[:3].cpu(), i1[:3].cpu()
+        with torch.no_grad():
+            loftr_ref.matcher_forward(sd, default_cfg, c0[:1], c1[:1])
+            times = []
+            for _ in range(2):
+                t = time.perf_counter()
+                ref = loftr_ref.matcher_forward(sd, default_cfg, c0, c1)
+                times.append(time.perf_counter() - t)
+        out["cpu_baseline"] = {"value": round(3 / min(times), 3), "unit": "LoFTR pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"3 pairs 256x256 in one oracle call (oracle/loftr_ref.py), 1 warm-up + best of 2, {len(ref['b_ids'])} matches"}
+    return out
+
+
+def driver_step_leg(vit, matcher, device, iters=10, cpu_baseline=True):
+    from pope_amd import synth
+    from pope_amd.crops import crop_proposals
+    from pope_amd.driver import locate_and_match, locate_and_match_u8, locate_match_pose_u8
+    from pope_amd.preprocess import gray_batch, set_torch_images
+    ref, frame, boxes, K0, K1 = synth.synthetic_frame_case()
+    frame_d = torch.from_numpy(frame).to(device)
+    ref_d = torch.from_numpy(ref).to(device)
+    crops = crop_proposals(frame_d, boxes, K1)["crops"]
+
+    def step_crops():
+        return locate_and_match_u8(vit, matcher, ref_d, crops)
+
+    def step_frame():
+        return locate_match_pose_u8(vit, matcher, ref_d, frame_d, boxes, K0, K1)
+
+    for _ in range(3):
+        step_crops()
+        step_frame()
+    ms_c, out = _wall_ms(step_crops, iters)
+    ms_f, full = _wall_ms(step_frame, iters)
+    # self-check: the reference's loop structure — P + 1 batch-1 DINOv2 forwards and three batch-1 LoFTR calls — on the same kernels
+    bad = []
+    x_ref, x_crops = set_torch_images(ref_d[None], center_crop=True), set_torch_images(crops, center_crop=True)
+    g_ref, g_crops = gray_batch(ref_d[None]), gray_batch(crops)
+    P = len(boxes)
+    cls_ref = vit(x_ref, is_training=True)["x_norm_clstoken"]
+    scores = torch.cat([torch.nn.functional.cosine_similarity(cls_ref, vit(x_crops[p:p + 1], is_training=True)["x_norm_clstoken"], dim=1, eps=1e-8)
+                        for p in range(P)])
+    if not torch.equal(scores, out["scores"]):
+        bad.append(f"cosine scores differ from {P} batch-1 forwards (max {float((scores - out['scores']).abs().max()):.2e})")
+    for s in range(3):
+        p = int(out["slot_index"][s])
+        if p < 0:
+            continue
+        one = {"image0": g_ref, "image1": g_crops[p:p + 1]}
+        matcher(one)
+        for key, name in (("mkpts0", "mkpts0_f"), ("mkpts1", "mkpts1_f"), ("mconf", "mconf")):
+            if not np.array_equal(out[key][s], one[name].cpu().numpy()):
+                bad.append(f"slot {s}: {key} differs from the batch-1 LoFTR call")
+    if not (np.array_equal(out["slot_index"], full["slot_index"]) and all(np.array_equal(out["mkpts1"][s], full["mkpts1"][s]) for s in range(3))):
+        bad.append("frame -> pose step and crop step disagree")
+    res = {"value": round(1e3 / ms_c, 1), "unit": "queries/s", "ms_per_step": round(ms_c, 3), "proposals": P,
+           "workload": "locate_and_match_u8: 1 reference + 8 proposal crops 256x256 uint8 -> Pillow-exact resize/crop to 196x196 -> one DINOv2 "
+                       "forward of 9 images -> CLS cosine + streaming top-3 -> one LoFTR Matcher call over the 3 occupied slots (256x256 gray)",
+           "matches_per_slot": [int(len(m)) for m in out["mconf"]], "best_proposal": int(out["best_proposal"]), "verified": not bad,
+           "from_frame": {"value": round(1e3 / ms_f, 1), "unit": "queries/s", "ms_per_step": round(ms_f, 3),
+                          "workload": "locate_match_pose_u8: 640x480 frame + 8 proposal boxes -> crops + K_crop (one launch) -> the step above -> "
+                                      "estimate_pose (five-point RANSAC + recoverPose on the GPU)",
+                          "pose_found": full["pose"] is not None,
+                          "pose_inliers": None if full["pose"] is None else int(full["pose"][2].sum())}}
+    if bad:
+        res["verify_failures"] = bad[:6]
+    if cpu_baseline:
+        from oracle import crop_ref, driver_ref
+        from pope_amd.dinov2_utils import _prep
+        from pope_amd.matcher import default_cfg
+        torch.set_num_threads(_cores())
+        vit_sd, m_sd = synth.synthetic_state_dict(seed=0), synth.synthetic_matcher_state_dict(seed=0)
+
+        def host_step():
+            cr = [crop_ref.crop_proposal(frame, b, K1)[0] for b in boxes]
+            xr = _prep(ref, (256, 256), (196, 196))[None]
+            xc = torch.stack([_prep(c, (256, 256), (196, 196)) for c in cr])
+            gray = lambda a: torch.from_numpy((((a[..., 0].astype(np.int64) * 1868 + a[..., 1].astype(np.int64) * 9617  # noqa: E731
+                                                 + a[..., 2].astype(np.int64) * 4899 + 8192) >> 14).astype(np.float32) / np.float32(255.0)))
+            return driver_ref.locate_and_match(vit_sd, m_sd, default_cfg, xr, xc, gray(ref)[None, None], torch.stack([gray(c) for c in cr])[:, None])
+
+        host_step()
+        t = time.perf_counter()
+        ref_out = host_step()
+        dt = time.perf_counter() - t
+        res["cpu_baseline"] = {"value": round(1 / dt, 3), "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "1 query (8 proposals) through oracle/crop_ref.py + the PIL host preprocessing + oracle/driver_ref.py "
+                                         f"(sequential batch-1 loop like the reference), 1 warm-up + 1 timed; slots {list(map(int, ref_out['slot_index']))}"}
+    return res
+
+
+def pose_leg(pipe, img0, img1, device, steps=3, cpu_baseline=True):
+    """extract + match + pose on the headline batch: estimate_pose_batch reads mkpts0_c / mkpts1_c / counts where the
+    matcher left them."""
+    from pope_amd.pose import estimate_pose_batch
+    K = np.array([[572.4114, 0, 315.0], [0, 573.57043, 238.0], [0, 0, 1.0]])   # LINEMOD intrinsics, principal point of the crop
+
+    def step():
+        out = pipe(img0, img1)
+        res = estimate_pose_batch(out["mkpts0_c"], out["mkpts1_c"], out["counts"], K, K, 0.5, 0.99)
+        return out, res
+
+    step()
+    ms, (out, res) = _wall_ms(step, steps)
+    k_ms, _ = _events_ms(lambda: estimate_pose_batch(out["mkpts0_c"], out["mkpts1_c"], out["counts"], K, K, 0.5, 0.99), 5)
+    info = res["info"].cpu().numpy()
+    n = img0.shape[0]
+    bad = []
+    off = np.concatenate([[0], np.cumsum(out["counts"].numpy())])
+    for k in sorted({0, n // 2, n - 1}):
+        one = estimate_pose_batch(out["mkpts0_c"][off[k]:off[k + 1]], out["mkpts1_c"][off[k]:off[k + 1]], out["counts"][k:k + 1], K, K, 0.5, 0.99)
+        if not (torch.equal(one["R"][0], res["R"][k]) and torch.equal(one["t"][0], res["t"][k])
+                and torch.equal(one["inliers"], res["inliers"][off[k]:off[k + 1]])):
+            bad.append(f"pair {k}: pose differs from its batch-1 call")
+    if int((info[:, 7] != 0).sum()):
+        bad.append("a pair's counts exceeded the match buffer")
+    r = {"value": round(n * 1e3 / ms, 1), "unit": "image-pairs/s", "ms_per_step": round(ms, 3), "steps": steps,
+         "workload": f"the headline step ({n} pairs: extract + dense match) followed by estimate_pose(mkpts0_c, mkpts1_c, K, K, 0.5, 0.99) for "
+                     "every pair in one launch (five-point RANSAC + recoverPose, fp64)",
+         "pose_kernel_ms": round(k_ms, 3), "pose_kernel_pairs_per_s": round(n * 1e3 / k_ms, 1),
+         "matches_per_pair_mean": round(float(info[:, 6].mean()), 1), "hypotheses_per_pair_mean": round(float(info[:, 2].mean()), 1),
+         "ransac_inliers_per_pair_mean": round(float(info[:, 1].mean()), 1), "poses_found": int((info[:, 0] > 0).sum()), "verified": not bad}
+    if bad:
+        r["verify_failures"] = bad[:6]
+    if cpu_baseline:
+        from oracle import pose_ref
+        a, b = out["mkpts0_c"][off[0]:off[1]].cpu().numpy(), out["mkpts1_c"][off[0]:off[1]].cpu().numpy()
+        t = time.perf_counter()
+        ret, oi = pose_ref.estimate_pose(a, b, K, K, 0.5, 0.99, return_info=True)
+        dt = time.perf_counter() - t
+        same = ret is not None and np.array_equal(ret[2], res["inliers"][off[0]:off[1]].cpu().numpy())
+        r["cpu_baseline"] = {"value": round(1 / dt, 3), "unit": "pairs/s (pose only)", "cores": 1, "kind": "port",
+                             "sample": f"pair 0 of the batch ({len(a)} matches, {oi.get('hypotheses')} hypotheses) through oracle/pose_ref.py "
+                                       f"(numpy fp64, scalar loops); inlier mask identical to the GPU's: {same}"}
+    return r

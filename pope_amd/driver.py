@@ -4,8 +4,10 @@ big GPU: what the reference does as P batch-1 DINOv2 forwards, P host round trip
 and three batch-1 LoFTR calls becomes one batched extraction, one cosine kernel, one host-side slot
 vote (order-dependent by definition) and ONE Matcher call over the occupied slots.
 
-Inputs are already-preprocessed tensors: SAM proposal generation, cv2 cropping / colour conversion and
-the pose solver are outside the accelerated path (SURVEY.md §8 'OUT').
+`locate_and_match` takes already-preprocessed tensors; `locate_and_match_u8` starts from the uint8 crops;
+`locate_match_pose_u8` is the whole per-pair body of the loop after SAM: frame + proposal boxes in, pose out — proposal
+crops and their intrinsics (crops.py), preprocessing (preprocess.py), DINOv2 vote, LoFTR matches and the essential-matrix
+RANSAC (pose.py) all on the card.  SAM proposal generation itself is upstream of the path (SURVEY.md §8 'OUT').
 """
 import numpy as np
 import torch
@@ -72,3 +74,31 @@ def locate_and_match_u8(dinov2_model, matcher, ref_bgr, crops_bgr, conf_thr=0.9)
     crops = torch.as_tensor(crops_bgr).to(dev)
     return locate_and_match(dinov2_model, matcher, set_torch_images(ref, center_crop=True), set_torch_images(crops, center_crop=True),
                             gray_batch(ref), gray_batch(crops), conf_thr)
+
+
+@torch.no_grad()
+def locate_match_pose_u8(dinov2_model, matcher, ref_bgr, frame_bgr, bboxes_xywh, K0, K1, conf_thr=0.9, ransac_thr=0.5, ransac_conf=0.99,
+                         out_size=256):
+    """eval_linemod_json.py:62-127,150-160 for one query: `ref_bgr` [H0, W0, 3] uint8 (the reference crop, `image0`),
+    `frame_bgr` [H, W, 3] uint8 (`image1`), `bboxes_xywh` [P, 4] SAM proposal boxes, `K0` / `K1` the two cameras.
+
+    proposals -> expanded boxes, 256 x 256 crops and their K (crops.crop_proposals, one launch) -> `locate_and_match_u8`
+    (DINOv2 vote + ONE LoFTR call over the occupied slots) -> `estimate_pose(mkpts0, mkpts1, K0, K_crop[best], 0.5, 0.99)`
+    on the best slot's matches (ALL of them: the 0.9 confidence only ranks the slots, :118-119,150-160).
+    Adds to `locate_and_match`'s dict: `boxes` [P, 4], `K_crops` [P, 3, 3], `pre_bbox`, `pre_K` (the chosen proposal's) and
+    `pose` = (R, t, inliers) or None."""
+    from .crops import crop_proposals
+    from .pose import estimate_pose
+    dev = next(dinov2_model.parameters()).device
+    frame = torch.as_tensor(frame_bgr).to(dev)
+    prop = crop_proposals(frame, bboxes_xywh, K1, out_size=out_size)
+    out = locate_and_match_u8(dinov2_model, matcher, ref_bgr, prop["crops"], conf_thr)
+    out["boxes"], out["K_crops"] = prop["boxes"], prop["K"]
+    best = out["best_proposal"]
+    if best < 0:       # no proposal entered a slot (the reference raises at :109)
+        out["pre_bbox"], out["pre_K"], out["pose"] = None, None, None
+        return out
+    out["pre_bbox"], out["pre_K"] = prop["boxes"][best], prop["K"][best]
+    s = out["best_slot"]
+    out["pose"] = estimate_pose(out["mkpts0"][s], out["mkpts1"][s], K0, out["pre_K"], ransac_thr, ransac_conf, device=dev)
+    return out

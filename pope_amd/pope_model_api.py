@@ -1,8 +1,9 @@
 """Hot-path subset of the reference façade `pope_model_api.py` (star-imported by the drivers,
 eval_linemod_json.py:1).  Exports, under the reference's names, everything of that namespace that
-lies on the accelerated path; names that belong to out-of-scope stages (SAM proposal
-generator, OpenCV pose solver, cv2 cropping helpers) are not re-implemented here — the reference's own
-modules keep providing them.
+lies on the accelerated path, including the caller-side geometry either side of it: the proposal crops
+and their intrinsics (`get_image_crop_resize`, `get_K_crop_resize`; batched: `crop_proposals`) and the pose solver
+(`estimate_pose`, `relative_pose_error`; batched: `estimate_pose_batch`).  Names that belong to out-of-scope stages (the SAM
+proposal generator, dataset helpers) are not re-implemented here — the reference's own modules keep providing them.
 
 Unlike the reference façade, importing this module has no side effects (the reference builds the
 LoFTR `matcher` singleton from weights/matcher.pth at import, pope_model_api.py:177-185).
@@ -15,11 +16,13 @@ import numpy as np  # noqa: F401
 import torch  # noqa: F401
 import torch.nn.functional as F  # noqa: F401
 
+from .crops import crop_proposals, expand_box, get_affine_transform, get_image_crop_resize, get_K_crop_resize  # noqa: F401
 from .dinov2_utils import get_cls_token_torch, load_dinov2_model, set_torch_image  # noqa: F401
-from .driver import locate_and_match  # noqa: F401
+from .driver import locate_and_match, locate_match_pose_u8  # noqa: F401
 from .matcher import CoarseMatching, Matcher, default_cfg, dense_match  # noqa: F401
 from .ops import cls_cosine, streaming_top3  # noqa: F401
 from .pipeline import PairPipeline, gather_counts, shard_range  # noqa: F401
+from .pose import estimate_pose, estimate_pose_batch, relative_pose_error  # noqa: F401
 
 
 def build_matcher(weights="weights/matcher.pth", device="cuda:0", state_dict=None):

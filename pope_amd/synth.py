@@ -289,3 +289,40 @@ def synthetic_pose_scene(n, seed, outlier=0.3, noise=0.0, K0=None, K1=None):
     inl = np.ones(n, bool)
     inl[bad] = False
     return k0.astype(np.float32), k1.astype(np.float32), K0, K1, R, t, inl
+
+
+def synthetic_frame_case(n_proposals=8, seed=31, frame_hw=(480, 640)):
+    """uint8 stand-in for one query of the drivers' loop starting at the raw frame (eval_linemod_json.py:62-90), without SAM:
+    a 256x256 BGR reference crop, a BGR frame and P proposal boxes (x, y, w, h).  Proposals 1 and 4 are 160x160 boxes whose
+    30 %-expanded window (256x256, scale 1: an integer crop) shows the reference shifted by a few pixels plus noise, so the
+    DINOv2 vote and the LoFTR matcher (synthetic weights) find them; the other boxes of assorted sizes — two leave the frame —
+    sit on unrelated texture.  Returns numpy (ref_bgr [256,256,3], frame_bgr [H,W,3], bboxes_xywh [P,4], K0 [3,3], K1 [3,3])."""
+    import numpy as np
+    H, W = frame_hw
+    g = torch.Generator().manual_seed(seed)
+
+    def texture(h, w):
+        base = torch.rand(1, 3, h // 4 + 1, w // 4 + 1, generator=g)
+        t = torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear", align_corners=False)[0]
+        return (0.7 * t + 0.3 * torch.rand(3, h, w, generator=g)).clamp_(0, 1)
+
+    ref = texture(256, 256)
+    frame = texture(H, W)
+    boxes = np.zeros((n_proposals, 4), np.int64)
+    planted = {1: ((96, 88), (8, 16), 0.01), 4: ((372, 60), (16, 8), 0.03)}      # (x, y) of the 160-box, shift, noise
+    rng = np.random.default_rng(seed)
+    for p in range(n_proposals):
+        if p in planted:
+            (x, y), shift, noise = planted[p]
+            win = (torch.roll(ref, shifts=shift, dims=(1, 2)) + noise * torch.randn(ref.shape, generator=g)).clamp_(0, 1)
+            frame[:, y - 48:y + 208, x - 48:x + 208] = win
+            boxes[p] = (x, y, 160, 160)
+        else:
+            w, h = int(rng.integers(40, 220)), int(rng.integers(40, 200))
+            boxes[p] = (int(rng.integers(-10, W - w + 30)), int(rng.integers(-10, H - h + 30)), w, h)
+    if n_proposals > 6:
+        boxes[6] = (W - 90, H - 70, 120, 100)       # leaves the frame at the bottom right
+    to_u8 = lambda t: (t.permute(1, 2, 0) * 255).round().to(torch.uint8).numpy()  # noqa: E731
+    K0 = np.array([[572.4114, 0, 128.0], [0, 573.57043, 128.0], [0, 0, 1.0]])
+    K1 = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1.0]])
+    return to_u8(ref), to_u8(frame), boxes, K0, K1

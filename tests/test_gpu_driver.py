@@ -62,3 +62,33 @@ def test_driver_step_with_fewer_than_three_candidates(dev, models):
     assert list(out["slot_index"]) == [0, -1, -1]
     assert out["matching_score"][1] == 0 and out["matching_score"][2] == 0 and out["mconf"][1].shape == (0,)
     assert out["best_slot"] == 0 and out["best_proposal"] == 0 and len(out["mconf"][0]) > 0
+
+
+def test_whole_query_from_frame_and_boxes_to_pose(dev, models):
+    """locate_match_pose_u8: frame + proposal boxes -> crops + K (one launch) -> preprocessing -> vote -> LoFTR -> pose,
+    against the same chain assembled from the oracles (oracle/crop_ref.py crops and intrinsics, oracle/pose_ref.py on the
+    published matches)."""
+    from oracle import crop_ref, pose_ref
+    from pope_amd import synth
+    from pope_amd.driver import locate_and_match_u8, locate_match_pose_u8
+    vit, matcher = models
+    ref, frame, boxes, K0, K1 = synth.synthetic_frame_case()
+    out = locate_match_pose_u8(vit, matcher, ref, frame, boxes, K0, K1)
+    crops_ref = np.stack([crop_ref.crop_proposal(frame, b, K1)[0] for b in boxes])
+    for p, b in enumerate(boxes):
+        _, Kc, box = crop_ref.crop_proposal(frame, b, K1)
+        assert np.array_equal(out["K_crops"][p], Kc) and np.array_equal(out["boxes"][p], box)
+    want = locate_and_match_u8(vit, matcher, ref, crops_ref)        # the oracle's crops through the same GPU stages
+    assert torch.equal(out["scores"], want["scores"]) and list(out["slot_index"]) == list(want["slot_index"])
+    assert out["best_proposal"] in (1, 4) and set(out["slot_index"]) >= {1, 4}     # the planted proposals win the vote
+    s = out["best_slot"]
+    assert np.array_equal(out["mkpts0"][s], want["mkpts0"][s]) and len(out["mconf"][s]) >= 8
+    assert np.array_equal(out["pre_K"], out["K_crops"][out["best_proposal"]])
+    ret = pose_ref.estimate_pose(out["mkpts0"][s], out["mkpts1"][s], K0, out["pre_K"], 0.5, 0.99)
+    assert (ret is None) == (out["pose"] is None)
+    if ret is not None:
+        R, t, inl = out["pose"]
+        print(f"best proposal {out['best_proposal']}: {len(out['mconf'][s])} matches, {int(inl.sum())} pose inliers")
+        assert np.array_equal(inl, ret[2]) and inl.sum() >= 5
+        np.testing.assert_allclose(R, ret[0], atol=1e-7)
+        np.testing.assert_allclose(t, ret[1], atol=1e-7)
