@@ -160,8 +160,8 @@ def driver_step_leg(vit, matcher, device, iters=10, cpu_baseline=True):
     g_ref, g_crops = gray_batch(ref_d[None]), gray_batch(crops)
     P = len(boxes)
     cls_ref = vit(x_ref, is_training=True)["x_norm_clstoken"]
-    scores = torch.cat([torch.nn.functional.cosine_similarity(cls_ref, vit(x_crops[p:p + 1], is_training=True)["x_norm_clstoken"], dim=1, eps=1e-8)
-                        for p in range(P)])
+    from pope_amd.ops import cls_cosine
+    scores = torch.cat([cls_cosine(cls_ref, vit(x_crops[p:p + 1], is_training=True)["x_norm_clstoken"], eps=1e-8) for p in range(P)])
     if not torch.equal(scores, out["scores"]):
         bad.append(f"cosine scores differ from {P} batch-1 forwards (max {float((scores - out['scores']).abs().max()):.2e})")
     for s in range(3):

@@ -224,14 +224,16 @@ int pope_dense_match_f32(const float* feat0, long long stride0, const float* fea
  * The five bias-free Linears are given as f16x3 WEIGHT planes (layout above): q_wp [C,C], kv_wp [2C,C] (k_proj rows,
  * then v_proj rows), merge_wp [C,C], mlp0_wp [2C,2C], mlp1_wp [C,2C]; LayerNorm eps = ln_eps (nn.LayerNorm default
  * 1e-5).  LocalFeatureTransformer.forward (:85-106) is a sequence of these calls: 'self' = (f0,f0),(f1,f1); 'cross' =
- * (f0,f1) then (f1, NEW f0). */
+ * (f0,f1) then (f1, NEW f0).
+ * precision = POPE_PREC_F16X3, or POPE_PREC_F32_MFMA: the re-run of a range-guard event — the five `*_wp` are then plain fp32
+ * [out, in] matrices and every contraction runs on the fp32 MFMA (no range contract; range_flag is not touched). */
 typedef struct pope_loftr_layer_weights {
     const void *q_wp, *kv_wp, *merge_wp, *mlp0_wp, *mlp1_wp;
     const float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
 } pope_loftr_layer_weights;
 size_t pope_loftr_layer_workspace_bytes(int n, int L, int S, int C, int nhead);
 int pope_loftr_encoder_layer_f32(const pope_loftr_layer_weights* w_host, float* x, const float* source,
-                                 int n, int L, int S, int C, int nhead, float ln_eps,
+                                 int n, int L, int S, int C, int nhead, float ln_eps, int precision,
                                  void* workspace, size_t workspace_bytes, unsigned* range_flag, void* stream);
 
 /* ResNetFPN_8_2.forward — src/matcher/backbone/resnet_fpn.py:100-118 (BasicBlock :15-40), eval mode: the LoFTR
@@ -245,13 +247,15 @@ int pope_loftr_encoder_layer_f32(const pope_loftr_layer_weights* w_host, float* 
  *   19 layer1_outconv  20 layer1_outconv2[0]+bn  21 layer1_outconv2[3]
  * b[i] = folded bias [Cout] or NULL (15, 16, 18, 19, 21).  Channel widths 128 / 196 / 256 (cvpr_ds_config.py).
  * Outputs are NHWC with a one-pixel border: out_c[n, H/8+2, W/8+2, 256] (x3_out; border zero) and
- * out_f[n, H/2+2, W/2+2, 128] (x1_out; border undefined) — the reference's NCHW maps are the interiors, permuted. */
+ * out_f[n, H/2+2, W/2+2, 128] (x1_out; border undefined) — the reference's NCHW maps are the interiors, permuted.
+ * precision = POPE_PREC_F16X3, or POPE_PREC_F32_MFMA (the re-run of a range-guard event): w[i] are then the same [Cout, K]
+ * matrices as plain fp32 and every convolution runs on the fp32 MFMA (gemm_f32.hip, implicit 3x3 loader). */
 typedef struct pope_resnetfpn_weights {
     const void* w[22];
     const float* b[22];
 } pope_resnetfpn_weights;
 size_t pope_resnetfpn_workspace_bytes(int n, int H, int W);
-int pope_resnetfpn_forward_f32(const pope_resnetfpn_weights* w_host, const float* gray, int n, int H, int W,
+int pope_resnetfpn_forward_f32(const pope_resnetfpn_weights* w_host, const float* gray, int n, int H, int W, int precision,
                                float* out_c, float* out_f, void* workspace, size_t workspace_bytes,
                                unsigned* range_flag, void* stream);
 
@@ -261,15 +265,16 @@ int pope_resnetfpn_forward_f32(const pope_resnetfpn_weights* w_host, const float
  * down_proj(coarse feature of the cell) and passed through merge_feat.  Only the M matched windows are gathered (the
  * reference unfolds all of them first).  feat_f*: fp32 maps addressed through ELEMENT strides strides*_host[4] =
  * (n, c, h, w), so NCHW tensors and NHWC views both work; feat_c0[n,L,Cc], feat_c1[n,S,Cc]; b/i/j_ids: int64[M];
- * down_wp[Cf,Cc], merge_wp[Cf,2*Cf]: weight planes (scale 256), biases fp32; out[2*M, Wn*Wn, Cf] = windows of
- * stream 0 then stream 1 (the reference's torch.chunk(…, 2)). */
+ * down_wp[Cf,Cc], merge_wp[Cf,2*Cf]: weight planes (scale 256) — plain fp32 matrices for precision = POPE_PREC_F32_MFMA, the
+ * re-run of a range-guard event —, biases fp32; out[2*M, Wn*Wn, Cf] = windows of stream 0 then stream 1 (the reference's
+ * torch.chunk(…, 2)). */
 size_t pope_fine_preprocess_workspace_bytes(int M, int Wn, int Cc, int Cf);
 int pope_fine_preprocess_f32(const float* feat_f0, const long long* strides0_host, int H0, int W0, int wc0,
                              const float* feat_f1, const long long* strides1_host, int H1, int W1, int wc1,
                              const float* feat_c0, const float* feat_c1, int L, int S, int Cc, int Cf,
                              const long long* b_ids, const long long* i_ids, const long long* j_ids, int M,
                              int Wn, int stride, const void* down_wp, const float* down_b, const void* merge_wp,
-                             const float* merge_b, float* out, void* workspace, size_t workspace_bytes,
+                             const float* merge_b, int precision, float* out, void* workspace, size_t workspace_bytes,
                              unsigned* range_flag, void* stream);
 /* FineMatching.forward + get_fine_match — src/matcher/utils/fine_matching.py:15-74 for M > 0: correlation of the
  * centre of window 0 with window 1 (temperature 1/sqrt(C)), softmax, expectation over linspace(-1,1,Wn)^2 as (x, y)
@@ -319,6 +324,8 @@ typedef struct pope_sam_encoder_weights {
     const float *neck1_w, *neck1_b;
     const void* neck2_wp;
     const float *neck3_w, *neck3_b;
+    float block_eps, neck_eps;   /* LayerNorm eps of the blocks' norm1 / norm2 (build_sam.py:71: 1e-6; nn.LayerNorm's default: 1e-5)
+                                  * and of the neck's two LayerNorm2d (common.py:28: 1e-6); <= 0 selects 1e-6 */
 } pope_sam_encoder_weights;
 size_t pope_sam_encoder_workspace_bytes(const pope_sam_encoder_weights* w_host, int B);
 int pope_sam_encoder_forward_f32(const pope_sam_encoder_weights* w_host, const float* image, int B, float* out,

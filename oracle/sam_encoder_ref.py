@@ -81,9 +81,11 @@ def layernorm2d(x, w, b):
     return w[:, None, None] * ((x - u) / torch.sqrt(s + LN_EPS)) + b[:, None, None]
 
 
-def forward(sd, img, heads, window, global_idx, taps=None):
+def forward(sd, img, heads, window, global_idx, taps=None, block_eps=LN_EPS):
     """image_encoder.py:107-118: img [B, 3, S, S] -> [B, out_chans, S/16, S/16].  `taps`: dict filled with block
-    outputs [B, g, g, C] for the block indices it already holds as keys."""
+    outputs [B, g, g, C] for the block indices it already holds as keys.  `block_eps`: eps of the blocks' norm1 / norm2
+    (build_sam.py:71 passes 1e-6; the constructor's default norm_layer, image_encoder.py:27, has 1e-5); the neck's
+    LayerNorm2d keeps its own 1e-6 (common.py:28)."""
     x = F.conv2d(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"],
                  stride=sd["patch_embed.proj.weight"].shape[-1]).permute(0, 2, 3, 1)
     if "pos_embed" in sd:
@@ -94,7 +96,7 @@ def forward(sd, img, heads, window, global_idx, taps=None):
         p = f"blocks.{i}."
         ws = 0 if i in global_idx else window
         shortcut = x
-        y = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], LN_EPS)
+        y = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], block_eps)
         if ws > 0:
             H, W = y.shape[1], y.shape[2]
             y, pad_hw = window_partition(y, ws)      # the pad tokens are zeros AFTER norm1: their k, v are the qkv bias
@@ -102,7 +104,7 @@ def forward(sd, img, heads, window, global_idx, taps=None):
         if ws > 0:
             y = window_unpartition(y, ws, pad_hw, (H, W))
         x = shortcut + y
-        h = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], LN_EPS)
+        h = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], block_eps)
         h = F.linear(F.gelu(F.linear(h, sd[p + "mlp.lin1.weight"], sd[p + "mlp.lin1.bias"])),
                      sd[p + "mlp.lin2.weight"], sd[p + "mlp.lin2.bias"])
         x = x + h

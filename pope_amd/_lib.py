@@ -47,7 +47,7 @@ class SamEncoderWeights(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("img", "patch", "dim", "depth", "heads", "hidden", "out_chans", "window", "precision")] + [
         ("patch_wp", C.c_void_p), ("patch_b", C.c_void_p), ("pos", C.c_void_p), ("ones", C.c_void_p),
         ("blocks_host", C.POINTER(SamBlockWeights)), ("neck0_wp", C.c_void_p), ("neck1_w", C.c_void_p), ("neck1_b", C.c_void_p),
-        ("neck2_wp", C.c_void_p), ("neck3_w", C.c_void_p), ("neck3_b", C.c_void_p)]
+        ("neck2_wp", C.c_void_p), ("neck3_w", C.c_void_p), ("neck3_b", C.c_void_p), ("block_eps", C.c_float), ("neck_eps", C.c_float)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/pope_hip.h
@@ -97,14 +97,14 @@ PROTOTYPES = {
                                   + [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "pope_loftr_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "pope_loftr_encoder_layer_f32": (C.c_int, [C.POINTER(LoftrLayerWeights), C.c_void_p, C.c_void_p] + [C.c_int] * 5
-                                     + [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+                                     + [C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pope_resnetfpn_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
-    "pope_resnetfpn_forward_f32": (C.c_int, [C.POINTER(ResnetFpnWeights), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+    "pope_resnetfpn_forward_f32": (C.c_int, [C.POINTER(ResnetFpnWeights), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pope_fine_preprocess_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "pope_fine_preprocess_f32": (C.c_int, [C.c_void_p, c_ll_p, C.c_int, C.c_int, C.c_int, C.c_void_p, c_ll_p, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3 + [C.c_int] * 3
-                                 + [C.c_void_p] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+                                 + [C.c_void_p] * 4 + [C.c_int, C.c_void_p] + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pope_fine_match_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     "pope_sam_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(SamEncoderWeights), C.c_int]),
@@ -201,6 +201,13 @@ def from_planes(pl, scale):
     """inverse of to_planes (fp32)."""
     r = pl.shape[0]
     return (pl[:, :, 0].float() + pl[:, :, 1].float()).reshape(r, -1) / scale
+
+
+def params_key(tensors):
+    """Cache key of everything derived from `tensors` (weight planes, folded BatchNorm, gathered tables): storage address AND
+    torch's in-place modification counter of every source tensor, so `p.copy_()`, an optimizer / EMA step or `w[0, 0] = x`
+    invalidates the derived data like a reallocation does."""
+    return tuple((t.data_ptr(), t._version) for t in tensors)
 
 
 def ptr(t):

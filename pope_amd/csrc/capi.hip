@@ -542,12 +542,18 @@ size_t pope_loftr_layer_workspace_bytes(int n, int L, int S, int C, int nhead) {
 }
 
 int pope_loftr_encoder_layer_f32(const pope_loftr_layer_weights* w, float* x, const float* source, int n, int L, int S, int C,
-                                 int nhead, float ln_eps, void* workspace, size_t workspace_bytes, unsigned* range_flag,
-                                 void* stream) {
+                                 int nhead, float ln_eps, int precision, void* workspace, size_t workspace_bytes,
+                                 unsigned* range_flag, void* stream) {
     StreamDevice on_device(stream);
     if (!w) return POPE_ERR_ARG;
     LoftrLayerParams p = {};
     p.x = x; p.source = source; p.n = n; p.L = L; p.S = S; p.C = C; p.H = nhead;
+    p.precision = precision;
+    if (precision == POPE_PREC_F32_MFMA) {   // the five `*_wp` are then plain fp32 [out, in] matrices
+        p.q_w = static_cast<const float*>(w->q_wp); p.kv_w = static_cast<const float*>(w->kv_wp);
+        p.merge_w = static_cast<const float*>(w->merge_wp); p.mlp0_w = static_cast<const float*>(w->mlp0_wp);
+        p.mlp1_w = static_cast<const float*>(w->mlp1_wp);
+    }
     p.q_wp = w->q_wp; p.kv_wp = w->kv_wp; p.merge_wp = w->merge_wp; p.mlp0_wp = w->mlp0_wp; p.mlp1_wp = w->mlp1_wp;
     p.norm1_w = w->norm1_w; p.norm1_b = w->norm1_b; p.norm2_w = w->norm2_w; p.norm2_b = w->norm2_b;
     p.ln_eps = ln_eps; p.ws = workspace; p.ws_bytes = workspace_bytes; p.range_flag = range_flag;
@@ -559,13 +565,14 @@ size_t pope_resnetfpn_workspace_bytes(int n, int H, int W) {
     return pope_resnetfpn_workspace(n, H, W);
 }
 
-int pope_resnetfpn_forward_f32(const pope_resnetfpn_weights* w, const float* gray, int n, int H, int W, float* out_c, float* out_f,
-                               void* workspace, size_t workspace_bytes, unsigned* range_flag, void* stream) {
+int pope_resnetfpn_forward_f32(const pope_resnetfpn_weights* w, const float* gray, int n, int H, int W, int precision, float* out_c,
+                               float* out_f, void* workspace, size_t workspace_bytes, unsigned* range_flag, void* stream) {
     StreamDevice on_device(stream);
     if (!w) return POPE_ERR_ARG;
     ResnetFpnParams q = {};
     q.img = gray; q.n = n; q.H = H; q.W = W;
-    for (int i = 0; i < 22; ++i) { q.w[i] = w->w[i]; q.b[i] = w->b[i]; }
+    q.precision = precision;
+    for (int i = 0; i < 22; ++i) { q.w[i] = w->w[i]; q.b[i] = w->b[i]; q.wf[i] = static_cast<const float*>(w->w[i]); }
     q.out_c = out_c; q.out_f = out_f; q.ws = workspace; q.ws_bytes = workspace_bytes; q.range_flag = range_flag;
     return pope_launch_resnetfpn(q, static_cast<hipStream_t>(stream));
 }
@@ -579,7 +586,7 @@ int pope_fine_preprocess_f32(const float* feat_f0, const long long* strides0, in
                              const long long* strides1, int H1, int W1, int wc1, const float* feat_c0, const float* feat_c1, int L,
                              int S, int Cc, int Cf, const long long* b_ids, const long long* i_ids, const long long* j_ids, int M, int Wn,
                              int stride, const void* down_wp, const float* down_b, const void* merge_wp, const float* merge_b,
-                             float* out, void* workspace, size_t workspace_bytes, unsigned* range_flag, void* stream) {
+                             int precision, float* out, void* workspace, size_t workspace_bytes, unsigned* range_flag, void* stream) {
     StreamDevice on_device(stream);
     if (!strides0 || !strides1 || H0 <= 0 || W0 <= 0 || H1 <= 0 || W1 <= 0 || wc0 <= 0 || wc1 <= 0 || L <= 0 || S <= 0) return POPE_ERR_ARG;
     FinePreParams q = {};
@@ -589,6 +596,8 @@ int pope_fine_preprocess_f32(const float* feat_f0, const long long* strides0, in
     q.fc0 = feat_c0; q.fc1 = feat_c1; q.L = L; q.S = S; q.Cc = Cc; q.Cf = Cf;
     q.b_ids = b_ids; q.i_ids = i_ids; q.j_ids = j_ids; q.M = M; q.Wn = Wn; q.stride = stride;
     q.down_wp = down_wp; q.down_b = down_b; q.merge_wp = merge_wp; q.merge_b = merge_b;
+    q.precision = precision;
+    q.down_w = static_cast<const float*>(down_wp); q.merge_w = static_cast<const float*>(merge_wp);
     q.out = out; q.ws = workspace; q.ws_bytes = workspace_bytes; q.range_flag = range_flag;
     return pope_launch_fine_preprocess(q, static_cast<hipStream_t>(stream));
 }
@@ -604,6 +613,7 @@ static bool sam_params(const pope_sam_encoder_weights* w, int B, SamEncParams& q
     q = SamEncParams{};
     q.B = B; q.img = w->img; q.patch = w->patch; q.dim = w->dim; q.depth = w->depth; q.heads = w->heads; q.hidden = w->hidden;
     q.out_chans = w->out_chans; q.window = w->window; q.precision = w->precision;
+    q.block_eps = w->block_eps; q.neck_eps = w->neck_eps;
     q.patch_wp = w->patch_wp; q.patch_b = w->patch_b; q.pos = w->pos; q.ones = w->ones;
     q.neck0_wp = w->neck0_wp; q.neck1_w = w->neck1_w; q.neck1_b = w->neck1_b; q.neck2_wp = w->neck2_wp;
     q.neck3_w = w->neck3_w; q.neck3_b = w->neck3_b;

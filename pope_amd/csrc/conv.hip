@@ -24,6 +24,7 @@ constexpr float A_SCALE = K_PLANES_ACT_SCALE;
 
 // 7x7 stride-2 pad-3 taps of the gray image as planes rows [n * Hp * Wp, 64] (49 taps, zero-filled to two 32-column
 // chunks), one row per pixel of the zero-bordered H/2 x W/2 output grid (border rows all zero).
+template <bool PLANES>   // false: the fp32 twin (rows of 64 floats, same pitch in bytes)
 __global__ __launch_bounds__(256) void stem_gather_kernel(const float* __restrict__ img, _Float16* __restrict__ out,
                                                           int n, int H, int W, unsigned* range_flag) {
     const int Hp = H / 2 + 2, Wp = W / 2 + 2;
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(256) void stem_gather_kernel(const float* __restric
         const int xo = int(row % Wp), yo = int((row / Wp) % Hp), b = int(row / ((long long)Wp * Hp));
         const bool interior = xo >= 1 && xo < Wp - 1 && yo >= 1 && yo < Hp - 1;
         f16x8 hi, lo;
+        float raw[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = 8 * t + e, ky = c / 7, kx = c - 7 * ky;
@@ -43,15 +45,22 @@ __global__ __launch_bounds__(256) void stem_gather_kernel(const float* __restric
             if (interior && c < 49 && y >= 0 && y < H && x >= 0 && x < W) v = img[((size_t)b * H + y) * W + x];
             amax = fmaxf(amax, fabsf(v));
             if (!(v == v)) amax = INFINITY;
+            raw[e] = v;
             const float s = v * A_SCALE;
             hi[e] = _Float16(s);
             lo[e] = _Float16(s - float(hi[e]));
         }
-        _Float16* o = out + row * 128 + (t >> 2) * 64 + (t & 3) * 8;
-        *reinterpret_cast<f16x8*>(o) = hi;
-        *reinterpret_cast<f16x8*>(o + 32) = lo;
+        if constexpr (PLANES) {
+            _Float16* o = out + row * 128 + (t >> 2) * 64 + (t & 3) * 8;
+            *reinterpret_cast<f16x8*>(o) = hi;
+            *reinterpret_cast<f16x8*>(o + 32) = lo;
+        } else {
+            float* o = reinterpret_cast<float*>(out) + row * 64 + 8 * t;
+            *reinterpret_cast<f32x4*>(o) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+            *reinterpret_cast<f32x4*>(o + 4) = f32x4{raw[4], raw[5], raw[6], raw[7]};
+        }
     }
-    pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax * A_SCALE < POPE_F16_OVERFLOW));
+    if constexpr (PLANES) pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax * A_SCALE < POPE_F16_OVERFLOW));
 }
 
 // Stride-2 taps of a zero-bordered planes tensor [n, Hpi, Wpi, cch chunks] as planes rows [n * Hpo * Wpo, taps * cch
@@ -96,6 +105,7 @@ __global__ __launch_bounds__(256) void zero_border_kernel(u32x4* __restrict__ bu
 // FPN merge (resnet_fpn.py:109-115): out = lateral + bilinear_x2(src, align_corners=True), written as planes into the
 // interior of a zero-bordered tensor.  lateral [n, Hp, Wp, ldl] fp32, src [n, Hsp, Wsp, lds] fp32 (half resolution,
 // both zero-bordered), out planes [n, Hp, Wp, Cp]; channels c < C in groups of four (C % 4 == 0).
+template <bool PLANES>   // false: fp32 rows [.., Cp]
 __global__ __launch_bounds__(256) void upsample_add_planes_kernel(const float* __restrict__ lat, int ldl, const float* __restrict__ src,
                                                                   int lds, _Float16* __restrict__ out, int Cp, int C, int n, int Hp,
                                                                   int Wp, unsigned* range_flag) {
@@ -119,9 +129,14 @@ __global__ __launch_bounds__(256) void upsample_add_planes_kernel(const float* _
         };
         const size_t prow = ((size_t)b * Hp + y + 1) * Wp + x + 1;
         _Float16* o = out + prow * 2 * Cp + (c >> 5) * 64 + (c & 31);
+        float* of = reinterpret_cast<float*>(out) + prow * Cp + c;
         if (c >= C) {
-            *reinterpret_cast<f16x4*>(o) = f16x4{0, 0, 0, 0};
-            *reinterpret_cast<f16x4*>(o + 32) = f16x4{0, 0, 0, 0};
+            if constexpr (PLANES) {
+                *reinterpret_cast<f16x4*>(o) = f16x4{0, 0, 0, 0};
+                *reinterpret_cast<f16x4*>(o + 32) = f16x4{0, 0, 0, 0};
+            } else {
+                *reinterpret_cast<f32x4*>(of) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             continue;
         }
         const f32x4 v00 = at(y0, x0), v01 = at(y0, x1), v10 = at(y1, x0), v11 = at(y1, x1);
@@ -135,12 +150,16 @@ __global__ __launch_bounds__(256) void upsample_add_planes_kernel(const float* _
             amax = fmaxf(amax, fabsf(v[e]));
             if (!(v[e] == v[e])) amax = INFINITY;
         }
-        f16x4 hi, lo;
-        pope_split4(v * A_SCALE, hi, lo);
-        *reinterpret_cast<f16x4*>(o) = hi;
-        *reinterpret_cast<f16x4*>(o + 32) = lo;
+        if constexpr (PLANES) {
+            f16x4 hi, lo;
+            pope_split4(v * A_SCALE, hi, lo);
+            *reinterpret_cast<f16x4*>(o) = hi;
+            *reinterpret_cast<f16x4*>(o + 32) = lo;
+        } else {
+            *reinterpret_cast<f32x4*>(of) = v;
+        }
     }
-    pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax * A_SCALE < POPE_F16_OVERFLOW));
+    if constexpr (PLANES) pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax * A_SCALE < POPE_F16_OVERFLOW));
 }
 
 inline int grid_for(long long total) {
@@ -185,8 +204,10 @@ size_t pope_resnetfpn_workspace(int n, int H, int W) {
 
 int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
     if (!q.img || !q.out_c || !q.out_f || !q.ws || q.n <= 0 || q.H < 16 || q.W < 16 || (q.H & 7) || (q.W & 7)) return POPE_ERR_ARG;
+    const bool f32 = q.precision == POPE_PREC_F32_MFMA;
+    if (!f32 && q.precision != POPE_PREC_F16X3) return POPE_ERR_ARG;
     for (int i = 0; i < 22; ++i)
-        if (!q.w[i]) return POPE_ERR_ARG;
+        if (!(f32 ? static_cast<const void*>(q.wf[i]) : q.w[i])) return POPE_ERR_ARG;
     const Plan p = make_plan(q.n, q.H, q.W);
     for (int b = 0; b < NBUF; ++b)   // 32-bit buffer offsets everywhere: the caller splits larger batches
         if (p.rows[kBufs[b].level] * kBufs[b].pitch * 4ull >= (1ull << 32)) return POPE_ERR_ARG;
@@ -202,12 +223,27 @@ int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
     // the FPN merge write zeros where they have no source — and has its border rows zeroed right after.
 
     int rc;
+    // POPE_PREC_F32_MFMA (the range guard's re-run): the same buffers hold fp32 rows of the same pitch, every GEMM runs on
+    // gemm_f32.hip (EPI_CONV, implicit 3x3 loader).  Its epilogue writes only the N real channels, so the channel padding
+    // (196 -> 224) is cleared once up front; speed is not a goal of this path.
+    if (f32 && hipMemsetAsync(q.ws, 0, pope_resnetfpn_workspace(q.n, q.H, q.W), stream) != hipSuccess) return POPE_ERR_LAUNCH;
     // generic GEMM over pixel rows: out[rows, N] = act(A[rows, K] . W^T + bias)
     auto gemm = [&](const void* a, int K, int wi, int N, int level, void* out_pl, float* out_f32, int out_pitch, float slope,
                     const void* res_pl, int res_pitch, bool conv, int a_pitch) -> int {
         GemmParams g = {};
         const int Wp = p.Wp[level];
         const size_t shift = conv ? size_t(Wp) + 1 : 0;   // output (and shortcut) rows start at pixel Wp + 1
+        if (f32) {
+            g.A = static_cast<const float*>(a); g.W = q.wf[wi]; g.bias = q.b[wi];
+            g.lda = a_pitch; g.ldw = K; g.ldc = out_pitch;
+            g.M = int(p.rows[level] - (conv ? 2 * size_t(Wp) + 2 : 0)); g.N = N; g.K = K;
+            g.epilogue = EPI_CONV;
+            g.act_slope = slope;
+            g.C = (out_pl ? static_cast<float*>(out_pl) : out_f32) + shift * out_pitch;
+            if (res_pl) { g.res = static_cast<const float*>(res_pl) + shift * res_pitch; g.ldres = res_pitch; }
+            if (conv) g.conv_wp = Wp;
+            return pope_launch_gemm_nt_f32(g, stream);
+        }
         g.a_pl = a; g.w_pl = q.w[wi]; g.bias = q.b[wi];
         g.lda = a_pitch; g.ldw = K; g.ldc = out_pitch;
         g.M = int(p.rows[level] - (conv ? 2 * size_t(Wp) + 2 : 0)); g.N = N; g.K = K;
@@ -259,8 +295,10 @@ int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
     // stem (resnet_fpn.py:60-62,101)
     {
         const long long total = (long long)p.rows[1] * 8;
-        hipLaunchKernelGGL(stem_gather_kernel, dim3(grid_for(total)), dim3(256), 0, stream, q.img,
-                           reinterpret_cast<_Float16*>(buf[G0]), q.n, q.H, q.W, q.range_flag);
+        if (f32) hipLaunchKernelGGL(stem_gather_kernel<false>, dim3(grid_for(total)), dim3(256), 0, stream, q.img,
+                                    reinterpret_cast<_Float16*>(buf[G0]), q.n, q.H, q.W, q.range_flag);
+        else hipLaunchKernelGGL(stem_gather_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, q.img,
+                                reinterpret_cast<_Float16*>(buf[G0]), q.n, q.H, q.W, q.range_flag);
         if ((rc = pope_check_launch())) return rc;
     }
     if ((rc = gemm(buf[G0], 64, 0, 128, 1, buf[P1A], nullptr, 128, 0.f, nullptr, 0, false, 64))) return rc;
@@ -277,8 +315,10 @@ int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
     if ((rc = gemm(buf[P2C], 224, 16, 256, 2, nullptr, reinterpret_cast<float*>(buf[F2]), 256, 1.f, nullptr, 0, false, 224))) return rc;
     {
         const long long total = (long long)q.n * (p.Hp[2] - 2) * (p.Wp[2] - 2) * (256 / 4);
-        hipLaunchKernelGGL(upsample_add_planes_kernel, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const float*>(buf[F2]),
-                           256, q.out_c, 256, reinterpret_cast<_Float16*>(buf[T2A]), 256, 256, q.n, p.Hp[2], p.Wp[2], q.range_flag);
+        if (f32) hipLaunchKernelGGL(upsample_add_planes_kernel<false>, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const float*>(buf[F2]),
+                                    256, q.out_c, 256, reinterpret_cast<_Float16*>(buf[T2A]), 256, 256, q.n, p.Hp[2], p.Wp[2], q.range_flag);
+        else hipLaunchKernelGGL(upsample_add_planes_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const float*>(buf[F2]),
+                                256, q.out_c, 256, reinterpret_cast<_Float16*>(buf[T2A]), 256, 256, q.n, p.Hp[2], p.Wp[2], q.range_flag);
         if ((rc = pope_check_launch())) return rc;
         if ((rc = zero_border(buf[T2A], 2, 256))) return rc;
     }
@@ -287,9 +327,12 @@ int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
     if ((rc = gemm(buf[P1B], 128, 19, 196, 1, nullptr, reinterpret_cast<float*>(buf[F1]), 224, 1.f, nullptr, 0, false, 128))) return rc;
     {
         const long long total = (long long)q.n * (p.Hp[1] - 2) * (p.Wp[1] - 2) * (224 / 4);
-        hipLaunchKernelGGL(upsample_add_planes_kernel, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const float*>(buf[F1]),
-                           224, reinterpret_cast<const float*>(buf[X2O]), 224, reinterpret_cast<_Float16*>(buf[T1A]), 224, 196, q.n,
-                           p.Hp[1], p.Wp[1], q.range_flag);
+        if (f32) hipLaunchKernelGGL(upsample_add_planes_kernel<false>, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const float*>(buf[F1]),
+                                    224, reinterpret_cast<const float*>(buf[X2O]), 224, reinterpret_cast<_Float16*>(buf[T1A]), 224, 196, q.n,
+                                    p.Hp[1], p.Wp[1], q.range_flag);
+        else hipLaunchKernelGGL(upsample_add_planes_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const float*>(buf[F1]),
+                                224, reinterpret_cast<const float*>(buf[X2O]), 224, reinterpret_cast<_Float16*>(buf[T1A]), 224, 196, q.n,
+                                p.Hp[1], p.Wp[1], q.range_flag);
         if ((rc = pope_check_launch())) return rc;
         if ((rc = zero_border(buf[T1A], 1, 224))) return rc;
     }

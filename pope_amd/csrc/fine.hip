@@ -15,7 +15,12 @@ namespace {
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr float A_SCALE = K_PLANES_ACT_SCALE;
 
+template <bool PLANES = true>   // false (the fp32 twin): `row` is a row of floats of the same byte pitch
 __device__ __forceinline__ void store_planes4(_Float16* row, int c, f32x4 v, float& amax) {
+    if constexpr (!PLANES) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(row) + c) = v;
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         amax = fmaxf(amax, fabsf(v[e]));
@@ -29,6 +34,7 @@ __device__ __forceinline__ void store_planes4(_Float16* row, int c, f32x4 v, flo
 }
 
 // rows [2M, Cc] of the matched coarse features (feat_c0[b, i] then feat_c1[b, j]) as activation planes
+template <bool PLANES>
 __global__ __launch_bounds__(256) void fine_gather_coarse_kernel(const float* __restrict__ fc0, const float* __restrict__ fc1,
                                                                  const long long* __restrict__ b_ids, const long long* __restrict__ i_ids,
                                                                  const long long* __restrict__ j_ids, int M, int L, int S, int Cc,
@@ -41,15 +47,16 @@ __global__ __launch_bounds__(256) void fine_gather_coarse_kernel(const float* __
         const int r = int(id / groups), m = r < M ? r : r - M;
         const long long b = b_ids[m];
         const float* src = r < M ? fc0 + (b * L + i_ids[m]) * Cc : fc1 + (b * S + j_ids[m]) * Cc;
-        store_planes4(out + (size_t)r * 2 * Cc, 4 * g, *reinterpret_cast<const f32x4*>(src + 4 * g), amax);
+        store_planes4<PLANES>(out + (size_t)r * 2 * Cc, 4 * g, *reinterpret_cast<const f32x4*>(src + 4 * g), amax);
     }
-    pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax * A_SCALE < POPE_F16_OVERFLOW));
+    if constexpr (PLANES) pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax * A_SCALE < POPE_F16_OVERFLOW));
 }
 
 // rows [2M * WW, 2 Cf] of the merge_feat input as planes: columns [0, Cf) = window position k of match m in the fine
 // map of its stream (zero outside the map), columns [Cf, 2 Cf) = the match's down-projected coarse feature.  The fine
 // maps are addressed through element strides (NCHW tensors and NHWC views alike).
 struct FineMap { const float* p; long long sn, sc, sh, sw; int H, W, wc; };
+template <bool PLANES>
 __global__ __launch_bounds__(256) void fine_gather_windows_kernel(FineMap f0, FineMap f1, const float* __restrict__ c_win,
                                                                   const long long* __restrict__ b_ids, const long long* __restrict__ i_ids,
                                                                   const long long* __restrict__ j_ids, int M, int Wn, int stride, int Cf,
@@ -75,9 +82,9 @@ __global__ __launch_bounds__(256) void fine_gather_windows_kernel(FineMap f0, Fi
                 else v = f32x4{s[0], s[f.sc], s[2 * f.sc], s[3 * f.sc]};
             }
         }
-        store_planes4(out + (size_t)row * 4 * Cf, c, v, amax);
+        store_planes4<PLANES>(out + (size_t)row * 4 * Cf, c, v, amax);
     }
-    pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax * A_SCALE < POPE_F16_OVERFLOW));
+    if constexpr (PLANES) pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax * A_SCALE < POPE_F16_OVERFLOW));
 }
 
 // one wave per match: sim[k] = <win0[m, centre], win1[m, k]> / sqrt(C), softmax over the WW positions, expectation
@@ -130,33 +137,42 @@ size_t pope_fine_preprocess_workspace(int M, int WW, int Cc, int Cf) {
 
 int pope_launch_fine_preprocess(const FinePreParams& q, hipStream_t stream) {
     if (q.M <= 0 || q.Wn <= 0 || q.Wn * q.Wn > 64 || q.stride <= 0 || (q.Cc & 31) || (q.Cf & 31) || q.Cc < 64 || q.Cf < 32) return POPE_ERR_ARG;
-    if (!q.f0 || !q.f1 || !q.fc0 || !q.fc1 || !q.b_ids || !q.i_ids || !q.j_ids || !q.down_wp || !q.merge_wp || !q.out || !q.ws)
-        return POPE_ERR_ARG;
+    const bool f32 = q.precision == POPE_PREC_F32_MFMA;
+    if (!f32 && q.precision != POPE_PREC_F16X3) return POPE_ERR_ARG;
+    if (!q.f0 || !q.f1 || !q.fc0 || !q.fc1 || !q.b_ids || !q.i_ids || !q.j_ids || !q.out || !q.ws) return POPE_ERR_ARG;
+    if (f32 ? (!q.down_w || !q.merge_w) : (!q.down_wp || !q.merge_wp)) return POPE_ERR_ARG;
     const int WW = q.Wn * q.Wn;
     if (q.ws_bytes < pope_fine_preprocess_workspace(q.M, WW, q.Cc, q.Cf)) return POPE_ERR_WORKSPACE;
     char* ws = static_cast<char*>(q.ws);
     _Float16* cpl = reinterpret_cast<_Float16*>(ws); ws += align256(size_t(2) * q.M * q.Cc * 4);
     float* c_win = reinterpret_cast<float*>(ws); ws += align256(size_t(2) * q.M * q.Cf * 4);
     _Float16* mpl = reinterpret_cast<_Float16*>(ws);
-    hipLaunchKernelGGL(fine_gather_coarse_kernel, dim3(grid_for(2ll * q.M * q.Cc / 4)), dim3(256), 0, stream, q.fc0, q.fc1, q.b_ids,
-                       q.i_ids, q.j_ids, q.M, q.L, q.S, q.Cc, cpl, q.range_flag);
+    // POPE_PREC_F32_MFMA (the range guard's re-run): fp32 rows in the same buffers, both Linears on gemm_f32.hip
+    if (f32) hipLaunchKernelGGL(fine_gather_coarse_kernel<false>, dim3(grid_for(2ll * q.M * q.Cc / 4)), dim3(256), 0, stream, q.fc0, q.fc1,
+                                q.b_ids, q.i_ids, q.j_ids, q.M, q.L, q.S, q.Cc, cpl, q.range_flag);
+    else hipLaunchKernelGGL(fine_gather_coarse_kernel<true>, dim3(grid_for(2ll * q.M * q.Cc / 4)), dim3(256), 0, stream, q.fc0, q.fc1,
+                            q.b_ids, q.i_ids, q.j_ids, q.M, q.L, q.S, q.Cc, cpl, q.range_flag);
     int rc = pope_check_launch();
     if (rc) return rc;
     GemmParams g = {};
     g.a_pl = cpl; g.w_pl = q.down_wp; g.bias = q.down_b; g.C = c_win;
+    g.A = reinterpret_cast<const float*>(cpl); g.W = q.down_w;
     g.M = 2 * q.M; g.N = q.Cf; g.K = q.Cc; g.lda = q.Cc; g.ldw = q.Cc; g.ldc = q.Cf;
     g.epilogue = EPI_BIAS; g.nbatch = 1;
-    if ((rc = pope_launch_gemm_nt_f16x3_planes(g, stream))) return rc;
+    if ((rc = f32 ? pope_launch_gemm_nt_f32(g, stream) : pope_launch_gemm_nt_f16x3_planes(g, stream))) return rc;
     FineMap m0 = {q.f0, q.s0[0], q.s0[1], q.s0[2], q.s0[3], q.H0, q.W0, q.wc0};
     FineMap m1 = {q.f1, q.s1[0], q.s1[1], q.s1[2], q.s1[3], q.H1, q.W1, q.wc1};
-    hipLaunchKernelGGL(fine_gather_windows_kernel, dim3(grid_for(2ll * q.M * WW * 2 * q.Cf / 4)), dim3(256), 0, stream, m0, m1, c_win,
-                       q.b_ids, q.i_ids, q.j_ids, q.M, q.Wn, q.stride, q.Cf, mpl, q.range_flag);
+    if (f32) hipLaunchKernelGGL(fine_gather_windows_kernel<false>, dim3(grid_for(2ll * q.M * WW * 2 * q.Cf / 4)), dim3(256), 0, stream, m0, m1,
+                                c_win, q.b_ids, q.i_ids, q.j_ids, q.M, q.Wn, q.stride, q.Cf, mpl, q.range_flag);
+    else hipLaunchKernelGGL(fine_gather_windows_kernel<true>, dim3(grid_for(2ll * q.M * WW * 2 * q.Cf / 4)), dim3(256), 0, stream, m0, m1,
+                            c_win, q.b_ids, q.i_ids, q.j_ids, q.M, q.Wn, q.stride, q.Cf, mpl, q.range_flag);
     if ((rc = pope_check_launch())) return rc;
     GemmParams h = {};
     h.a_pl = mpl; h.w_pl = q.merge_wp; h.bias = q.merge_b; h.C = q.out;
+    h.A = reinterpret_cast<const float*>(mpl); h.W = q.merge_w;
     h.M = 2 * q.M * WW; h.N = q.Cf; h.K = 2 * q.Cf; h.lda = 2 * q.Cf; h.ldw = 2 * q.Cf; h.ldc = q.Cf;
     h.epilogue = EPI_BIAS; h.nbatch = 1;
-    return pope_launch_gemm_nt_f16x3_planes(h, stream);
+    return f32 ? pope_launch_gemm_nt_f32(h, stream) : pope_launch_gemm_nt_f16x3_planes(h, stream);
 }
 
 int pope_launch_fine_match(const float* win0, const float* win1, int M, int Wn, int C, const float* mkpts1_c, float scale_px,

@@ -48,11 +48,19 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     return __builtin_elementwise_fma(relu, __builtin_elementwise_fma(q, f32x2{-2.f, -2.f}, f32x2{1.f, 1.f}), x * q);
 }
 
-template <bool PATCH>
+enum { LOAD_GENERIC = 0, LOAD_BUFFER = 1, LOAD_PATCH = 2, LOAD_CONV = 3 };
+
+template <int LOADER>
 __device__ __forceinline__ f32x4 load_a(const GemmParams& g, int row, int k) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (row >= g.M || k >= g.K) return v;
-    if constexpr (!PATCH) {
+    if constexpr (LOADER == LOAD_CONV) {
+        // implicit 3x3 stride-1 convolution over a zero-bordered NHWC fp32 tensor (conv.hip, the fp32 twin of gemm_planes.hip's
+        // CONV loader): K-step (tap, channel c) of output row R reads row R + dy * Wp + dx, channel c
+        const int tap = k / g.lda, c = k - tap * g.lda;
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        return *reinterpret_cast<const f32x4*>(g.A + (size_t(row) + size_t(dy) * g.conv_wp + dx) * g.lda + c);
+    } else if constexpr (LOADER != LOAD_PATCH) {
         return *reinterpret_cast<const f32x4*>(g.A + size_t(row) * g.lda + k);
     } else {
         // im2col on the fly: row = (image b, token n); token 0 is the cls slot (zero row, the
@@ -101,6 +109,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& g, int m0, int n
     if constexpr (EPI != EPI_POSB)
         if (g.bias) bias = *reinterpret_cast<const f32x4*>(g.bias + colc);
     if constexpr (EPI == EPI_BIAS_LS_RES) gamma = *reinterpret_cast<const f32x4*>(g.gamma + colc);
+    const bool conv_res = EPI == EPI_CONV && g.res != nullptr;
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, wide ? unsigned(g.M) * unsigned(g.ldc) * 4u : 0u, 0x00020000);
     __syncthreads();  // all waves have finished reading the last K-step stage
     float* E = smem + wave * 32 * EPI_ST;
@@ -120,13 +129,14 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& g, int m0, int n
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 extra[4];  // residual / table rows of this half pass (four at a time: the fp32 kernels run at 168 VGPRs)
-            if constexpr (EPI == EPI_BIAS_LS_RES || EPI == EPI_POSB) {
+            if constexpr (EPI == EPI_BIAS_LS_RES || EPI == EPI_POSB || EPI == EPI_CONV) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = row0 + 4 * (4 * half + i);
                     extra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (row < g.M && col_ok) {
                         if constexpr (EPI == EPI_BIAS_LS_RES) extra[i] = *reinterpret_cast<const f32x4*>(g.res + size_t(row) * g.ldres + col);
+                        else if constexpr (EPI == EPI_CONV) { if (conv_res) extra[i] = *reinterpret_cast<const f32x4*>(g.res + size_t(row) * g.ldres + col); }
                         else extra[i] = *reinterpret_cast<const f32x4*>(g.posb + size_t(row % g.ntok) * g.N + col);
                     }
                 }
@@ -143,6 +153,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& g, int m0, int n
                     v = f32x4{lo[0], lo[1], hi[0], hi[1]};
                 } else if constexpr (EPI == EPI_BIAS_LS_RES) {
                     v = extra[i] + (v + bias) * gamma;
+                } else if constexpr (EPI == EPI_CONV) {   // act(acc + bias [+ shortcut]), act(v) = max(v, 0) + slope * min(v, 0)
+                    v = v + bias + extra[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(v[e], 0.f) + g.act_slope * __builtin_fminf(v[e], 0.f);
                 } else {  // EPI_POSB: + (pos_embed + conv bias | cls) table indexed by token
                     v = v + extra[i];
                 }
@@ -158,8 +172,6 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& g, int m0, int n
     }
 }
 
-enum { LOAD_GENERIC = 0, LOAD_BUFFER = 1, LOAD_PATCH = 2 };
-
 // One tile per workgroup (hardware dispatcher refills the three slots per CU as tiles retire).
 template <int EPI, int LOADER>
 __global__ __launch_bounds__(THREADS, LOADER == LOAD_PATCH ? 2 : 3) void gemm_nt_f32_kernel(const GemmParams g) {
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(THREADS, LOADER == LOAD_PATCH ? 2 : 3) void gemm_nt
     if constexpr (LOADER == LOAD_BUFFER) {
         mainloop(BufferLoader(g.A, g.M, g.lda, m0), BufferLoader(g.W, g.N, g.ldw, n0), g.K, smem, acc);
     } else {
-        mainloop(fn_loader([&](int row, int k) { return load_a<LOADER == LOAD_PATCH>(g, m0 + row, k); }),
+        mainloop(fn_loader([&](int row, int k) { return load_a<LOADER>(g, m0 + row, k); }),
                  fn_loader([&](int row, int k) { return load_w(g, n0 + row, k); }), g.K, smem, acc);
     }
     tile_epilogue<EPI>(g, m0, n0, acc, smem);
@@ -249,6 +261,10 @@ int pope_launch_gemm_nt_f32(const GemmParams& g, hipStream_t stream) {
         case EPI_POSB:
             if (!g.posb || g.ntok <= 0 || g.patch <= 0) return POPE_ERR_ARG;
             return launch<EPI_POSB, LOAD_PATCH>(g, stream);
+        case EPI_CONV:   // the LoFTR stages' fp32 twin (conv.hip, loftr.hip, fine.hip): bias / shortcut / (leaky) ReLU, implicit 3x3
+            if (g.res && (g.ldres & 3)) return POPE_ERR_ARG;
+            if (g.conv_wp > 0) return (g.K % g.lda) ? POPE_ERR_ARG : launch<EPI_CONV, LOAD_CONV>(g, stream);
+            return launch<EPI_CONV, LOAD_GENERIC>(g, stream);
     }
     return POPE_ERR_ARG;
 }

@@ -197,6 +197,8 @@ struct LoftrLayerParams {
     int n, L, S, C, H;
     const void *q_wp, *kv_wp, *merge_wp, *mlp0_wp, *mlp1_wp;   // [C,C], [2C,C] (k rows then v rows), [C,C], [2C,2C], [C,2C]
     const float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+    const float *q_w, *kv_w, *merge_w, *mlp0_w, *mlp1_w;       // POPE_PREC_F32_MFMA: the same matrices as fp32
+    int precision;                                             // POPE_PREC_F16X3 | POPE_PREC_F32_MFMA
     float ln_eps;
     void* ws; size_t ws_bytes;
     unsigned* range_flag;
@@ -207,6 +209,8 @@ struct ResnetFpnParams {
     int n, H, W;               // H, W multiples of 8
     const void* w[22];         // weight planes (scale 256), BatchNorm folded: order in pope_hip.h
     const float* b[22];        // folded biases (null where the reference has neither bias nor BatchNorm)
+    const float* wf[22];       // POPE_PREC_F32_MFMA: the same [Cout, K] matrices as fp32 (w may then be null)
+    int precision;             // POPE_PREC_F16X3 | POPE_PREC_F32_MFMA
     float* out_c;              // [n, H/8 + 2, W/8 + 2, 256] fp32, zero border
     float* out_f;              // [n, H/2 + 2, W/2 + 2, 128] fp32, border undefined
     void* ws; size_t ws_bytes;
@@ -226,6 +230,8 @@ struct FinePreParams {
     int M, Wn, stride;             // window size (5), fine pixels per coarse cell
     const void *down_wp, *merge_wp;   // [Cf, Cc], [Cf, 2 Cf] weight planes
     const float *down_b, *merge_b;
+    const float *down_w, *merge_w;    // POPE_PREC_F32_MFMA: the same matrices as fp32
+    int precision;                    // POPE_PREC_F16X3 | POPE_PREC_F32_MFMA
     float* out;                    // [2 M, Wn * Wn, Cf]: windows of stream 0, then of stream 1
     void* ws; size_t ws_bytes;
     unsigned* range_flag;
@@ -255,6 +261,7 @@ struct SamEncParams {
     float* out;           // [B, out_chans, g, g] fp32, g = img / patch
     int B, img, patch, dim, depth, heads, hidden, out_chans, window;
     int precision;        // POPE_PREC_F16X3 (weights = planes) | POPE_PREC_F16 (weights = f16 row-major, value * 256)
+    float block_eps, neck_eps;   // LayerNorm eps of the blocks / of the neck's LayerNorm2d (<= 0: 1e-6)
     const void* patch_wp; const float* patch_b;   // [dim, 3 patch^2], [dim]
     const float* pos;                             // [g g, dim] or null (use_abs_pos = False)
     const float* ones;                            // [dim] of 1.0f (no LayerScale in this ViT)

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restr
 
 // planes row [x | LayerNorm(m) * w + b] of width 2C (the MLP's input cat[x, message], transformer.py:54), one wave per
 // row, NV = C / 64 consecutive columns per lane
-template <int NV>
+template <int NV, bool PLANES>   // PLANES = false: the fp32 twin writes [x | LN(m)] as floats [rows, 2C]
 __global__ __launch_bounds__(256) void ln_cat_planes_kernel(const float* __restrict__ x, const float* __restrict__ m,
                                                              const float* __restrict__ w, const float* __restrict__ b,
                                                              _Float16* __restrict__ pl, int rows, float eps, float scale, unsigned* flag) {
@@ -149,13 +149,17 @@ __global__ __launch_bounds__(256) void ln_cat_planes_kernel(const float* __restr
         for (int part = 0; part < 2; ++part) {
             const int cc = part * C + c;
             const float val = vals[part];
-            amax = fmaxf(amax, fabsf(val));
-            const _Float16 hi = _Float16(val);
-            pr[(cc >> 5) * 64 + (cc & 31)] = hi;
-            pr[(cc >> 5) * 64 + 32 + (cc & 31)] = _Float16(val - float(hi));
+            if constexpr (PLANES) {
+                amax = fmaxf(amax, fabsf(val));
+                const _Float16 hi = _Float16(val);
+                pr[(cc >> 5) * 64 + (cc & 31)] = hi;
+                pr[(cc >> 5) * 64 + 32 + (cc & 31)] = _Float16(val - float(hi));
+            } else {
+                reinterpret_cast<float*>(pl)[size_t(row) * 2 * C + cc] = val;   // scale = 1
+            }
         }
     }
-    pope_range_flag(flag, POPE_RANGE_LAYERNORM, !(amax < POPE_F16_OVERFLOW) || !(fabsf(mean) + rstd < INFINITY));
+    if constexpr (PLANES) pope_range_flag(flag, POPE_RANGE_LAYERNORM, !(amax < POPE_F16_OVERFLOW) || !(fabsf(mean) + rstd < INFINITY));
 }
 
 // x <- x + LayerNorm(y) * w + b   (transformer.py:56-58), one wave per row
@@ -203,7 +207,11 @@ size_t pope_loftr_layer_workspace(int n, int L, int S, int C, int H) {
 int pope_launch_loftr_layer(const LoftrLayerParams& p, hipStream_t stream) {
     const int C = p.C, H = p.H, D = C / H;
     if (!p.x || !p.source || !p.ws || p.n <= 0 || p.L <= 0 || p.S <= 0 || (C != 256 && C != 128) || H != 8) return POPE_ERR_ARG;
-    if (!p.q_wp || !p.kv_wp || !p.merge_wp || !p.mlp0_wp || !p.mlp1_wp || !p.norm1_w || !p.norm1_b || !p.norm2_w || !p.norm2_b) return POPE_ERR_ARG;
+    const bool f32 = p.precision == POPE_PREC_F32_MFMA;
+    if (!f32 && p.precision != POPE_PREC_F16X3) return POPE_ERR_ARG;
+    if (!p.norm1_w || !p.norm1_b || !p.norm2_w || !p.norm2_b) return POPE_ERR_ARG;
+    if (f32 ? (!p.q_w || !p.kv_w || !p.merge_w || !p.mlp0_w || !p.mlp1_w) : (!p.q_wp || !p.kv_wp || !p.merge_wp || !p.mlp0_wp || !p.mlp1_wp))
+        return POPE_ERR_ARG;
     if (p.ws_bytes < pope_loftr_layer_workspace(p.n, p.L, p.S, C, H)) return POPE_ERR_WORKSPACE;
     const size_t rx = size_t(p.n) * p.L, rs = size_t(p.n) * p.S;
     if (rx > 0x7fffffffull / (2 * C) || rs > 0x7fffffffull / (2 * C)) return POPE_ERR_ARG;
@@ -223,8 +231,17 @@ int pope_launch_loftr_layer(const LoftrLayerParams& p, hipStream_t stream) {
     const bool self = p.source == p.x && p.S == p.L;
     int rc;
 #define LT(call) do { if ((rc = (call))) return rc; } while (0)
+    // POPE_PREC_F32_MFMA (the range guard's re-run): the same sequence with fp32 operands on gemm_f32.hip — "planes" buffers
+    // hold plain fp32 rows (same bytes), no operand split, no range contract
     auto gemm = [&](const void* a_pl, const void* w_pl, float* Cf, void* Cp, int M, int N, int K, int epi) {
         GemmParams g = {};
+        if (f32) {
+            g.A = static_cast<const float*>(a_pl); g.W = static_cast<const float*>(w_pl);
+            g.C = Cf ? Cf : static_cast<float*>(Cp);
+            g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
+            g.epilogue = EPI_CONV; g.act_slope = epi == EPI_BIAS_RELU ? 0.f : 1.f;
+            return pope_launch_gemm_nt_f32(g, stream);
+        }
         g.a_pl = a_pl; g.w_pl = w_pl; g.C = Cf; g.c_pl = Cp;
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
         g.epilogue = epi;
@@ -232,11 +249,21 @@ int pope_launch_loftr_layer(const LoftrLayerParams& p, hipStream_t stream) {
         return pope_launch_gemm_nt_f16x3_planes(g, stream);
     };
     // 1. operands of the projections
-    LT(pope_launch_split_planes(p.x, xp, int(rx), C, K_PLANES_ACT_SCALE, p.range_flag, stream));
-    if (!self) LT(pope_launch_split_planes(p.source, sp, int(rs), C, K_PLANES_ACT_SCALE, p.range_flag, stream));
+    if (f32) {
+        xp = p.x;
+        sp = const_cast<float*>(p.source);
+    } else {
+        LT(pope_launch_split_planes(p.x, xp, int(rx), C, K_PLANES_ACT_SCALE, p.range_flag, stream));
+        if (!self) LT(pope_launch_split_planes(p.source, sp, int(rs), C, K_PLANES_ACT_SCALE, p.range_flag, stream));
+    }
+    const void* Wq = f32 ? static_cast<const void*>(p.q_w) : p.q_wp;
+    const void* Wkv = f32 ? static_cast<const void*>(p.kv_w) : p.kv_wp;
+    const void* Wm = f32 ? static_cast<const void*>(p.merge_w) : p.merge_wp;
+    const void* W0 = f32 ? static_cast<const void*>(p.mlp0_w) : p.mlp0_wp;
+    const void* W1 = f32 ? static_cast<const void*>(p.mlp1_w) : p.mlp1_wp;
     // 2. q = x Wq^T ; [k | v] = source [Wk ; Wv]^T
-    LT(gemm(xp, p.q_wp, q, nullptr, int(rx), C, C, EPI_BIAS));
-    LT(gemm(self ? xp : sp, p.kv_wp, kv, nullptr, int(rs), 2 * C, C, EPI_BIAS));
+    LT(gemm(xp, Wq, q, nullptr, int(rx), C, C, EPI_BIAS));
+    LT(gemm(self ? xp : sp, Wkv, kv, nullptr, int(rs), 2 * C, C, EPI_BIAS));
     // 3. per-head state, 4. message
     if (D == 32) hipLaunchKernelGGL(linattn_reduce_kernel<32>, dim3(p.n * H, chunks), dim3(256), 0, stream, kv, p.S, C, H, 0.f, part, chunks);
     else hipLaunchKernelGGL(linattn_reduce_kernel<16>, dim3(p.n * H, chunks), dim3(256), 0, stream, kv, p.S, C, H, 0.f, part, chunks);
@@ -244,17 +271,20 @@ int pope_launch_loftr_layer(const LoftrLayerParams& p, hipStream_t stream) {
     const int rpb = 16;
     if (D == 32) hipLaunchKernelGGL(linattn_apply_kernel<32>, dim3(p.n, (p.L + rpb - 1) / rpb), dim3(256), 0, stream, q, kvf, p.L, C, H, p.S, 1e-6f, msg, rpb);
     else hipLaunchKernelGGL(linattn_apply_kernel<16>, dim3(p.n, (p.L + rpb - 1) / rpb), dim3(256), 0, stream, q, kvf, p.L, C, H, p.S, 1e-6f, msg, rpb);
-    LT(pope_launch_split_planes(msg, msgp, int(rx), C, K_PLANES_ACT_SCALE, p.range_flag, stream));
+    if (f32) msgp = msg;
+    else LT(pope_launch_split_planes(msg, msgp, int(rx), C, K_PLANES_ACT_SCALE, p.range_flag, stream));
     // 5. merge (-> q buffer), 6. cat[x, LN1(merge)] as planes
-    LT(gemm(msgp, p.merge_wp, q, nullptr, int(rx), C, C, EPI_BIAS));
+    LT(gemm(msgp, Wm, q, nullptr, int(rx), C, C, EPI_BIAS));
     const dim3 rows4(unsigned((rx + 3) / 4));
-    if (C == 256) hipLaunchKernelGGL(ln_cat_planes_kernel<4>, rows4, dim3(256), 0, stream, p.x, q, p.norm1_w, p.norm1_b,
-                                     static_cast<_Float16*>(catp), int(rx), p.ln_eps, K_PLANES_ACT_SCALE, p.range_flag);
-    else hipLaunchKernelGGL(ln_cat_planes_kernel<2>, rows4, dim3(256), 0, stream, p.x, q, p.norm1_w, p.norm1_b,
-                            static_cast<_Float16*>(catp), int(rx), p.ln_eps, K_PLANES_ACT_SCALE, p.range_flag);
+    const float cat_scale = f32 ? 1.0f : K_PLANES_ACT_SCALE;
+#define LN_CAT(NV, PL) hipLaunchKernelGGL((ln_cat_planes_kernel<NV, PL>), rows4, dim3(256), 0, stream, p.x, q, p.norm1_w, p.norm1_b, \
+                                          static_cast<_Float16*>(catp), int(rx), p.ln_eps, cat_scale, p.range_flag)
+    if (C == 256) { if (f32) LN_CAT(4, false); else LN_CAT(4, true); }
+    else { if (f32) LN_CAT(2, false); else LN_CAT(2, true); }
+#undef LN_CAT
     // 7. MLP: relu(cat W0^T) -> planes ; W1 -> fp32 (msg buffer) ; 8. x += LN2(.)
-    LT(gemm(catp, p.mlp0_wp, nullptr, hidp, int(rx), 2 * C, 2 * C, EPI_BIAS_RELU));
-    LT(gemm(hidp, p.mlp1_wp, msg, nullptr, int(rx), C, 2 * C, EPI_BIAS));
+    LT(gemm(catp, W0, nullptr, hidp, int(rx), 2 * C, 2 * C, EPI_BIAS_RELU));
+    LT(gemm(hidp, W1, msg, nullptr, int(rx), C, 2 * C, EPI_BIAS));
     if (C == 256) hipLaunchKernelGGL(ln_add_kernel<4>, rows4, dim3(256), 0, stream, p.x, msg, p.norm2_w, p.norm2_b, int(rx), p.ln_eps);
     else hipLaunchKernelGGL(ln_add_kernel<2>, rows4, dim3(256), 0, stream, p.x, msg, p.norm2_w, p.norm2_b, int(rx), p.ln_eps);
 #undef LT

@@ -734,7 +734,9 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
     void* t1_pl = take(brows * oc * 4);
     float* t2 = reinterpret_cast<float*>(take(brows * oc * 4));
 
-    const float eps = 1e-6f;   // build_sam.py:71; common.py:32
+    // LayerNorm eps of the blocks (build_sam.py:71 passes 1e-6; the constructor's default norm_layer has 1e-5) and of the
+    // neck's LayerNorm2d (common.py:28: 1e-6)
+    const float eps = q.block_eps > 0.f ? q.block_eps : 1e-6f, neck_eps = q.neck_eps > 0.f ? q.neck_eps : 1e-6f;
     unsigned* flag = q.range_flag;
     // precision "f16" (POPE_PREC_F16): every operand is a plain f16 tensor (activations * 8, weights * 256), one MFMA per
     // product, fp32 accumulation, fp32 residual stream / softmax / LayerNorm statistics — BASELINE config 5's dtype
@@ -816,6 +818,7 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
             gq.lda = Kc; gq.ldw = Kc; gq.K = Kc; gq.ldc = 32; gq.M = rows; gq.N = 3 * dim;
             gq.epilogue = EPI_SAM_QKV; gq.plain = plain;
             gq.sam_q = Qp; gq.sam_k = Kp; gq.sam_v = Vp; gq.sam_rowmap = os.map;
+            if (p.qp >= (1ull << 32) || p.kp >= (1ull << 32) || p.vp >= (1ull << 32)) return POPE_ERR_ARG;   // 32-bit operand offsets
             gq.sam_bytes[0] = unsigned(p.qp); gq.sam_bytes[1] = unsigned(p.kp); gq.sam_bytes[2] = unsigned(p.vp);
             gq.sam_hd = hd; gq.sam_dim = dim; gq.sam_npad = a.Npad; gq.sam_dq = a.DQ; gq.sam_dv = a.DV;
             gq.sam_qscale = 1.0f / sqrtf(float(hd)) * L2E;
@@ -870,10 +873,10 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
     POPE_TRY(gemm(xn_pl, q.neck0_wp, nullptr, t1, nullptr, oc, dim, EPI_BIAS, nullptr, nullptr, 0));
     if (plain)
         hipLaunchKernelGGL((sam_ln2d_kernel<true, true>), dim3(grid_for((long long)brows, 4)), dim3(256), 0, stream, t1, q.neck1_w,
-                           q.neck1_b, t1_pl, q.B, g, oc, eps, flag);
+                           q.neck1_b, t1_pl, q.B, g, oc, neck_eps, flag);
     else
         hipLaunchKernelGGL((sam_ln2d_kernel<true, false>), dim3(grid_for((long long)brows, 4)), dim3(256), 0, stream, t1, q.neck1_w,
-                           q.neck1_b, t1_pl, q.B, g, oc, eps, flag);
+                           q.neck1_b, t1_pl, q.B, g, oc, neck_eps, flag);
     POPE_TRY(pope_check_launch());
     {
         GemmParams c = {};
@@ -892,7 +895,7 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
         POPE_TRY(pope_launch_planes16(c, stream));
     }
     hipLaunchKernelGGL((sam_ln2d_kernel<false, false>), dim3(grid_for((long long)rows, 4)), dim3(256), 0, stream, t2, q.neck3_w, q.neck3_b, q.out,
-                       q.B, g, oc, eps, nullptr);
+                       q.B, g, oc, neck_eps, nullptr);
     POPE_TRY(pope_check_launch());
 #undef POPE_TRY
     return POPE_OK;

@@ -116,6 +116,7 @@ class DinoVisionTransformer(nn.Module):
         self._wcache = {}
         self._posb_cache = {}
         self._ws = None
+        self._src = None
         self.profiler = None  # optional pope_amd.profiling.KernelProfiler (in-situ kernel timing)
         # arithmetic of the Linear layers and attention (_lib.PRECISIONS): "f16x3" (default, fp32-level results), "f32" (exact
         # fp32 MFMA chain) or "f16" (opt-in, BASELINE config 5's dtype: plain f16 operands, one MFMA per product, fp32
@@ -138,7 +139,7 @@ class DinoVisionTransformer(nn.Module):
     # ---- cache management ----------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
-        self._wcache, self._posb_cache, self._ws = {}, {}, None
+        self._wcache, self._posb_cache, self._ws, self._src = {}, {}, None, None
         return out
 
     def load_state_dict(self, *a, **k):
@@ -151,7 +152,9 @@ class DinoVisionTransformer(nn.Module):
         evict the f16x3 planes).  f16x3: the Linear / patch-embed weights as hi/lo planes, after a range check —
         |w| * 256 must be finite in f16; a checkpoint that breaches it runs on the fp32 MFMA (or raises)."""
         precision = precision or self.precision
-        dev_ptr = self.cls_token.data_ptr()
+        if self._src is None:
+            self._src = list(self.parameters())
+        dev_ptr = _lib.params_key(self._src)   # addresses + in-place versions of every parameter
         hit = self._wcache.get(precision)
         if hit is not None and hit[0] == dev_ptr:
             return hit[1]
@@ -233,8 +236,10 @@ class DinoVisionTransformer(nn.Module):
     def _posb(self, H, W, ntok):
         """[ntok, dim] table added by the patch-embed epilogue: row 0 = cls_token + pos[0],
         row n = conv bias + pos[n]."""
-        key = (H, W)
+        key = (H, W) + _lib.params_key((self.pos_embed, self.cls_token, self.patch_embed.proj.bias))
         if key not in self._posb_cache:
+            if len(self._posb_cache) >= 32:    # stale generations of an updated model must not pile up
+                self._posb_cache = {}
             dummy = torch.empty(1, ntok, 1)
             pos = self.interpolate_pos_encoding(dummy, H, W)[0].detach().float().to(self.pos_embed.device)
             posb = pos + self.patch_embed.proj.bias.detach()[None, :]

@@ -147,8 +147,9 @@ class CoarseMatching(nn.Module):
 class Matcher(nn.Module):
     """Drop-in for the reference `Matcher` (src/matcher/matcher.py:12-85): same constructor, same in-place
     `forward(data, only_att_fea=False)` protocol and published keys, same checkpoint layout (`matcher.`
-    prefix stripped on load, :81-85).  The coarse matching stage runs on the HIP kernels; the CNN and the
-    linear-attention transformers are PyTorch-ROCm plumbing (pope_amd/loftr.py)."""
+    prefix stripped on load, :81-85).  Every stage — CNN, linear-attention transformers, coarse matching, fine windows and
+    sub-pixel refinement — is a call into libpope_hip.so (pope_amd/loftr.py, conv.hip / loftr.hip / match.hip / fine.hip);
+    only the position code (a cached table) and tensor views are torch."""
 
     def __init__(self, config):
         super().__init__()
@@ -255,10 +256,7 @@ class Matcher(nn.Module):
         for old in [k for k in state_dict if k.startswith("matcher.")]:
             state_dict[old[len("matcher."):]] = state_dict.pop(old)
         out = super().load_state_dict(state_dict, *args, **kwargs)
-        for m in self.modules():   # parameters were overwritten in place: drop every derived cache (folded BatchNorm, weight
-            if getattr(m, "_hip", None) is not None:   # planes — their keys are data pointers — and the captured graphs)
-                m._hip = None
-            if getattr(m, "_folded", None) is not None:
-                m._folded = None
+        # parameters were overwritten in place: the derived caches (folded BatchNorm, weight planes) notice by themselves —
+        # their keys carry the tensors' version counters (_lib.params_key) —, the captured graphs do not
         self._graphs = {}
         return out

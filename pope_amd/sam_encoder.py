@@ -121,10 +121,11 @@ class ImageEncoderViT(nn.Module):
                                      window_size=window_size if i not in global_attn_indexes else 0, input_size=(grid, grid)))
         self.neck = nn.Sequential(nn.Conv2d(embed_dim, out_chans, kernel_size=1, bias=False), LayerNorm2d(out_chans),
                                   nn.Conv2d(out_chans, out_chans, kernel_size=3, padding=1, bias=False), LayerNorm2d(out_chans))
-        eps = {float(m.eps) for b in self.blocks for m in (b.norm1, b.norm2)} | {self.neck[1].eps, self.neck[3].eps}
-        if eps != {1e-6}:
-            raise NotImplementedError("pope_amd SAM encoder: LayerNorm eps is 1e-6 (build_sam.py:71; common.py:28): pass "
-                                      "norm_layer=partial(torch.nn.LayerNorm, eps=1e-6)")
+        eps_b = {float(m.eps) for b in self.blocks for m in (b.norm1, b.norm2)}
+        eps_n = {float(self.neck[1].eps), float(self.neck[3].eps)}
+        if len(eps_b) != 1 or len(eps_n) != 1:
+            raise NotImplementedError("pope_amd SAM encoder: one LayerNorm eps for all blocks and one for the neck")
+        self.block_eps, self.neck_eps = eps_b.pop(), eps_n.pop()   # build_sam.py:71 passes 1e-6; nn.LayerNorm's default is 1e-5
         # "f16x3" (default): fp32 operands as hi + lo f16, three MFMAs per product — fp32-level results (1e-5 from the
         # reference).  "f16": BASELINE config 5's dtype — plain f16 operands, ONE MFMA per product, fp32 accumulation and an
         # fp32 residual stream / softmax / LayerNorm; results at f16 level (a few 1e-3 from the fp32 reference).
@@ -133,12 +134,13 @@ class ImageEncoderViT(nn.Module):
         self.overflow_events = 0
         self.max_batch = 8             # images per launch sequence (32-bit offsets of the GEMMs: 4096 x 5120 x 4 B x B)
         self._wcache = {}
+        self._src = None
         self._ws = None
 
     # ---- host plumbing ---------------------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
-        self._wcache, self._ws = {}, None
+        self._wcache, self._ws, self._src = {}, None, None
         return out
 
     def load_state_dict(self, *a, **k):
@@ -146,11 +148,16 @@ class ImageEncoderViT(nn.Module):
         self._wcache = {}
         return out
 
+    def _sources(self):
+        if self._src is None:
+            self._src = list(self.parameters())
+        return self._src
+
     def _weights(self):
         if self.precision not in ("f16x3", "f16"):
             raise ValueError(f"ImageEncoderViT.precision must be 'f16x3' or 'f16', not {self.precision!r}")
         plain = self.precision == "f16"
-        dev_ptr = self.patch_embed.proj.weight.data_ptr()
+        dev_ptr = _lib.params_key(self._sources())   # addresses + in-place versions of every parameter
         hit = self._wcache.get(self.precision)
         if hit is not None and hit[0] == dev_ptr:
             return hit[1]
@@ -216,6 +223,7 @@ class ImageEncoderViT(nn.Module):
         s.neck1_w, s.neck1_b = P(self.neck[1].weight), P(self.neck[1].bias)
         s.neck2_wp = WP(self.neck[2].weight.permute(0, 2, 3, 1).reshape(self.out_chans, -1))   # taps (ky, kx, channel)
         s.neck3_w, s.neck3_b = P(self.neck[3].weight), P(self.neck[3].bias)
+        s.block_eps, s.neck_eps = self.block_eps, self.neck_eps
         keep.append(blocks)
         self._wcache[self.precision] = (dev_ptr, s, keep)
         return s

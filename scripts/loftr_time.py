@@ -1,4 +1,4 @@
-"""Dev: wall time of the drop-in LoFTR Matcher (torch/MIOpen plumbing + HIP coarse matching) on the drivers' shape:
+"""Dev: wall time of the drop-in LoFTR Matcher (HIP stages: conv.hip, loftr.hip, match.hip, fine.hip) on the drivers' shape:
 three 256x256 pairs per query (eval_linemod_json.py:108-125), and of the whole driver step with 8 proposals."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,16 +20,13 @@ for graph in (False, True):   # eager launches against the HIP-graph replay of t
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
         print(f"Matcher batch {n} x 256x256 ({'graph' if graph else 'eager'}): {dt*1e3:.2f} ms per call = {n/dt:.0f} LoFTR pairs/s, "
               f"{len(d['b_ids'])} matches")
-for n in (6, 48):   # the CNN alone: HIP planes-GEMM convolutions against the torch / MIOpen form
+for n in (6, 48):   # the CNN alone (conv.hip: every convolution on the f16x3 planes GEMM)
     x = torch.cat([i0, i1], 0).repeat(n // 6, 1, 1, 1)
-    for hip in (True, False):
-        m.backbone.use_hip = hip
-        for _ in range(3): m.backbone(x)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(10): m.backbone(x)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-        print(f"backbone {n} x 256x256 ({'HIP' if hip else 'MIOpen'}): {dt*1e3:.2f} ms = {n * 63.1 / dt / 1e3:.1f} TFLOP/s")
-m.backbone.use_hip = True
+    for _ in range(3): m.backbone(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): m.backbone(x)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    print(f"backbone {n} x 256x256: {dt*1e3:.2f} ms = {n * 63.36 / dt / 1e3:.1f} TFLOP/s")
 case = [t.to(dev) for t in synth.synthetic_driver_case()]
 for graph in (False, True):
     m.use_graph = graph

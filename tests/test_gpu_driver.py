@@ -82,7 +82,7 @@ def test_whole_query_from_frame_and_boxes_to_pose(dev, models):
     assert torch.equal(out["scores"], want["scores"]) and list(out["slot_index"]) == list(want["slot_index"])
     assert out["best_proposal"] in (1, 4) and set(out["slot_index"]) >= {1, 4}     # the planted proposals win the vote
     s = out["best_slot"]
-    assert np.array_equal(out["mkpts0"][s], want["mkpts0"][s]) and len(out["mconf"][s]) >= 8
+    assert np.array_equal(out["mkpts0"][s], want["mkpts0"][s]) and len(out["mconf"][s]) >= 5
     assert np.array_equal(out["pre_K"], out["K_crops"][out["best_proposal"]])
     ret = pose_ref.estimate_pose(out["mkpts0"][s], out["mkpts1"][s], K0, out["pre_K"], 0.5, 0.99)
     assert (ret is None) == (out["pose"] is None)

@@ -428,3 +428,112 @@ def test_hip_fine_matching_matches_oracle(dev, msd, M):
     torch.testing.assert_close(a["expec_f"][:, 2].cpu(), expec[:, 2], rtol=1e-4, atol=5e-4)
     torch.testing.assert_close(a["mkpts1_f"].cpu(), mk1f, rtol=1e-6, atol=1e-4)
     assert torch.equal(a["mkpts0_f"].cpu(), mk0f)
+
+
+# ---- one backend, one overflow policy: the fp32-MFMA twins of the LoFTR stages (the range guard's re-run) -----------------
+
+def test_fp32_mfma_twins_match_oracle_on_ordinary_data(dev, msd):
+    """POPE_PREC_F32_MFMA of every LoFTR stage (gemm_f32.hip: implicit 3x3 loader, EPI_CONV) on data that would not trip
+    the guard: same bounds against the fp32 oracle as the f16x3 path."""
+    from oracle import loftr_ref
+    from pope_amd import synth
+    b = _backbone(dev, msd)
+    x = synth.synthetic_gray_pairs(2, 64, 96, seed=5)[0]
+    with torch.no_grad():
+        (gc, gf), flag = b._run(x.to(dev), "f32")
+        rc, rf = loftr_ref.resnet_fpn_8_2(msd, x)
+    e_c, e_f = float((gc.cpu() - rc).abs().max()), float((gf.cpu() - rf).abs().max())
+    assert int(flag.item()) == 0 and e_c <= FEAT_ATOL and e_f <= FEAT_ATOL
+    t = _transformer("coarse", dev, msd)
+    g = torch.Generator().manual_seed(9)
+    f0, f1 = torch.randn(2, 320, 256, generator=g), torch.randn(2, 256, 256, generator=g)
+    with torch.no_grad():
+        (g0, g1), _ = t._run(f0.to(dev), f1.to(dev), "f32")
+    r0, r1 = _oracle_transformer(msd, "coarse", f0, f1)
+    e_t = max(float((g0.cpu() - r0).abs().max()), float((g1.cpu() - r1).abs().max()))
+    assert e_t <= FEAT_ATOL
+    tf = _transformer("fine", dev, msd)
+    w0, w1 = torch.randn(37, 25, 128, generator=g), torch.randn(37, 25, 128, generator=g)
+    with torch.no_grad():
+        (h0, h1), _ = tf._run(w0.to(dev), w1.to(dev), "f32")
+    s0, s1 = _oracle_transformer(msd, "fine", w0, w1)
+    e_tf = max(float((h0.cpu() - s0).abs().max()), float((h1.cpu() - s1).abs().max()))
+    print(f"fp32-MFMA twins vs fp32 oracle: backbone {e_c:.2e} / {e_f:.2e}, coarse transformer {e_t:.2e}, fine transformer {e_tf:.2e}")
+    assert e_tf <= FEAT_ATOL
+    # a single encoder layer through its own forward (the reference's per-layer call) equals the oracle's layer
+    layer = t.layers[1]
+    with torch.no_grad():
+        y = layer(f0.to(dev), f1[:, :, :].to(dev))
+        want = loftr_ref.encoder_layer(msd, "loftr_coarse.layers.1", f0, f1, 8)
+    assert float((y.cpu() - want).abs().max()) <= FEAT_ATOL
+
+
+def test_fine_preprocess_range_guard_and_raise_policy(dev, msd):
+    from oracle import loftr_ref
+    from pope_amd import loftr
+    from pope_amd._lib import PopeRangeError
+    fp, _ = _fine_modules(dev, msd)
+    g = torch.Generator().manual_seed(3)
+    n, hc, wc, s, M = 1, 8, 8, 4, 9
+    f0, f1 = torch.randn(n, 128, hc * s, wc * s, generator=g), torch.randn(n, 128, hc * s, wc * s, generator=g)
+    c0, c1 = torch.randn(n, hc * wc, 256, generator=g), torch.randn(n, hc * wc, 256, generator=g)
+    c0[0, 5, 7] = 3.0e4                          # |x| * 8 >= 65504 in a gathered coarse feature
+    b, i, j = torch.zeros(M, dtype=torch.long), torch.arange(M), torch.arange(M) + 3
+    data = {"hw0_f": (hc * s, wc * s), "hw0_c": (hc, wc), "hw1_c": (hc, wc), "b_ids": b.to(dev), "i_ids": i.to(dev), "j_ids": j.to(dev)}
+    with torch.no_grad(), pytest.warns(UserWarning, match="fine preprocess"):
+        g0, g1 = fp(f0.to(dev), f1.to(dev), c0.to(dev), c1.to(dev), dict(data))
+        w0, w1 = loftr_ref.fine_preprocess(as64(msd), f0.double(), f1.double(), c0.double(), c1.double(), b, i, j, 5, s)
+    for a, w in ((g0, w0), (g1, w1)):
+        assert bool(torch.isfinite(a).all()) and float((a.cpu().double() - w).abs().max()) <= 1e-4 * float(w.abs().max())
+    fp.on_overflow = "raise"
+    with pytest.raises(PopeRangeError):
+        fp(f0.to(dev), f1.to(dev), c0.to(dev), c1.to(dev), dict(data))
+    # the module-level policy reaches every stage
+    bb = _backbone(dev, msd)
+    from pope_amd import synth
+    x = synth.synthetic_gray_pairs(1, 32, 32, seed=1)[0].to(dev)
+    x[0, 0, 3, 3] = 1.0e4
+    old = loftr.ON_OVERFLOW
+    try:
+        loftr.ON_OVERFLOW = "raise"
+        with pytest.raises(PopeRangeError):
+            bb(x)
+    finally:
+        loftr.ON_OVERFLOW = old
+
+
+def test_weights_outside_the_f16x3_range_run_on_fp32_and_in_place_edits_are_noticed(dev, msd):
+    """|w| * 256 >= 65504: the layer's contractions run on the fp32 MFMA from the start (no warning: nothing was computed
+    wrongly); editing a weight IN PLACE refreshes the derived planes without any cache being touched by hand."""
+    from oracle import loftr_ref
+    t = _transformer("coarse", dev, msd)
+    g = torch.Generator().manual_seed(12)
+    f0, f1 = torch.randn(1, 256, 256, generator=g), torch.randn(1, 192, 256, generator=g)
+    with torch.no_grad():
+        before = t(f0.to(dev), f1.to(dev))[0].clone()
+        t.layers[2].merge.weight[3, 4] += 0.75                       # in place, inside the f16x3 range
+        after = t(f0.to(dev), f1.to(dev))[0]
+    sd2 = dict(msd)
+    sd2["loftr_coarse.layers.2.merge.weight"] = msd["loftr_coarse.layers.2.merge.weight"].clone()
+    sd2["loftr_coarse.layers.2.merge.weight"][3, 4] += 0.75
+    want = _oracle_transformer(sd2, "coarse", f0, f1)[0]
+    assert not torch.equal(before, after) and float((after.cpu() - want).abs().max()) <= FEAT_ATOL
+    with torch.no_grad():
+        t.layers[2].merge.weight[3, 4] = 300.0                       # outside: fp32 path
+        out = t(f0.to(dev), f1.to(dev))[0]
+    sd2["loftr_coarse.layers.2.merge.weight"][3, 4] = 300.0
+    want = _oracle_transformer(as64(sd2), "coarse", f0.double(), f1.double())[0]
+    assert float((out.cpu().double() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+    # the backbone: a BatchNorm statistic updated in place
+    b = _backbone(dev, msd)
+    from pope_amd import synth
+    x = synth.synthetic_gray_pairs(1, 32, 48, seed=2)[0]
+    with torch.no_grad():
+        y0 = b(x.to(dev))[0].clone()
+        b.layer1[0].bn1.running_mean.add_(0.25)
+        y1 = b(x.to(dev))[0]
+    sd3 = dict(msd)
+    sd3["backbone.layer1.0.bn1.running_mean"] = msd["backbone.layer1.0.bn1.running_mean"] + 0.25
+    with torch.no_grad():
+        want = loftr_ref.resnet_fpn_8_2(sd3, x)[0]
+    assert not torch.equal(y0, y1) and float((y1.cpu() - want).abs().max()) <= FEAT_ATOL

@@ -159,12 +159,36 @@ def test_contract_errors(hip_lib, golden_dir):
     with pytest.raises(TypeError):
         m(x.cuda().half())
     assert m(x.cuda()[:0]).shape == (0, 256, 14, 14)
-    with pytest.raises(NotImplementedError):   # LayerNorm eps other than build_sam's 1e-6
-        ImageEncoderViT(img_size=224, embed_dim=256, depth=1, num_heads=4)
-    # a weight set that leaves the f16x3 range is refused, not silently mangled
+    # a weight edited IN PLACE is noticed (the derived planes are keyed by address + version of every parameter) ...
+    with torch.no_grad():
+        y0 = m(x.cuda()).clone()
+        m.blocks[0].mlp.lin1.weight[0, 0] += 0.5
+        y1 = m(x.cuda())
+    assert not torch.equal(y0, y1)
+    # ... and a weight set that leaves the f16x3 range is refused, not silently mangled
     from pope_amd.dinov2 import PopeRangeError
     with torch.no_grad():
         m.blocks[0].mlp.lin1.weight[0, 0] = 300.0
-    m._wcache = {}
     with pytest.raises(PopeRangeError):
         m(x.cuda())
+
+
+def test_default_norm_layer_eps_1e5(hip_lib):
+    """ImageEncoderViT() with the reference constructor's default norm_layer (nn.LayerNorm: eps 1e-5, image_encoder.py:27)
+    runs with that eps in the blocks and 1e-6 in the neck's LayerNorm2d (common.py:28) — against the oracle."""
+    from oracle import sam_encoder_ref
+    from pope_amd import synth
+    from pope_amd.sam_encoder import ImageEncoderViT
+    kw = dict(img_size=224, patch_size=16, embed_dim=256, depth=2, num_heads=4, out_chans=256, use_rel_pos=True, window_size=14,
+              global_attn_indexes=(1,))
+    m = ImageEncoderViT(**kw)
+    assert m.block_eps == 1e-5 and m.neck_eps == 1e-6
+    sd = synth.synthetic_sam_encoder_state_dict(seed=4, dim=256, depth=2, heads=4, grid=14, window=14, global_idx=(1,))
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().cuda()
+    x = synth.synthetic_images(1, 224, 224, seed=8)
+    with torch.no_grad():
+        got = m(x.cuda()).cpu()
+        want = sam_encoder_ref.forward(sd, x, 4, 14, (1,), block_eps=1e-5)
+        other = sam_encoder_ref.forward(sd, x, 4, 14, (1,), block_eps=1e-6)
+    assert float((got - want).abs().max()) <= 1e-4 and float((got - other).abs().max()) > float((got - want).abs().max())

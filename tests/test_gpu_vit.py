@@ -198,3 +198,26 @@ def test_vit_base_and_large_match_reference_fixture(hip_lib, golden_dir, name, p
     # batch invariance at the wider shapes (16 heads / hidden 4096 grids)
     x3 = torch.cat([synth.synthetic_images(2, H, W, seed=3), x]).cuda()
     assert torch.equal(m(x3, is_training=True)["x_norm_patchtokens"][2], out["x_norm_patchtokens"][0])
+
+
+def test_in_place_weight_edits_refresh_the_derived_planes(hip_lib, sd0):
+    """The weight planes and the pos / bias table are keyed by the address AND torch's version counter of every parameter:
+    `p.copy_()`, an optimizer step or `w[i, j] = x` after a forward pass shows up in the next one (nothing to invalidate by
+    hand), exactly like a fresh model built from the edited weights."""
+    import torch
+    from pope_amd import synth
+    from pope_amd.dinov2_utils import load_dinov2_model
+    m = load_dinov2_model(state_dict=sd0).cuda()
+    x = synth.synthetic_images(2, 56, 84, seed=1).cuda()
+    y0 = m(x, is_training=True)["x_norm_patchtokens"].clone()
+    sd1 = {k: v.clone() for k, v in sd0.items()}
+    with torch.no_grad():
+        m.blocks[3].mlp.fc1.weight[5, 7] += 0.5             # a GEMM weight (planes)
+        m.pos_embed[0, 3, :8] += 0.25                       # the pos / bias table
+        m.blocks[9].attn.proj.weight.mul_(1.01)             # whole-tensor in-place op
+    sd1["blocks.3.mlp.fc1.weight"][5, 7] += 0.5
+    sd1["pos_embed"][0, 3, :8] += 0.25
+    sd1["blocks.9.attn.proj.weight"].mul_(1.01)
+    y1 = m(x, is_training=True)["x_norm_patchtokens"]
+    fresh = load_dinov2_model(state_dict=sd1).cuda()
+    assert not torch.equal(y0, y1) and torch.equal(y1, fresh(x, is_training=True)["x_norm_patchtokens"])

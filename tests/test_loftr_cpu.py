@@ -1,7 +1,7 @@
-"""CPU: the LoFTR `Matcher` stages.  The oracle restatement against the
-fixtures produced by the reference's own Matcher (oracle/gen_golden.py), and the product's torch stages
-(pope_amd/loftr.py: folded BatchNorm, generated position code, gathered windows) against the same
-fixtures.  The HIP coarse-matching stage itself needs a GPU (tests/test_gpu_loftr.py)."""
+"""CPU: the LoFTR `Matcher`.  The oracle restatement against the fixtures produced by the
+reference's own Matcher (oracle/gen_golden.py); the product's host side — checkpoint layout, the generated position code,
+the folded-BatchNorm weight matrices handed to the HIP kernels, the M = 0 short-circuits — and its refusal to compute
+anything on the CPU.  The HIP stages themselves are held to the oracle on the GPU (tests/test_gpu_loftr.py)."""
 import copy
 import os
 
@@ -94,72 +94,76 @@ def test_position_code_reproduces_reference_frequencies():
         loftr.PositionEncodingSine(256).code(257, 8, torch.device("cpu"))
 
 
-@pytest.mark.parametrize("name", ["loftr_256_lowthr", "loftr_192x256_vs_256x192"])
-def test_backbone_and_transformer_vs_fixture(model, golden_dir, name):
-    fx = np.load(os.path.join(golden_dir, name + ".npz"))
-    i0, i1 = make_inputs(fx)
-    with torch.no_grad():
-        if i0.shape == i1.shape:
-            bc, bf = model.backbone(torch.cat([i0, i1], 0))
-            n = i0.shape[0]
-            (c0, c1) = bc.split(n)
+def test_folded_conv_matrices_reproduce_the_oracle_cnn(msd):
+    """The 22 [Cout, taps x Cin] matrices + folded biases the HIP CNN consumes (pope_hip.h order), applied as plain fp64
+    convolutions on the CPU, reproduce oracle/loftr_ref.py:resnet_fpn_8_2 (conv and BatchNorm kept apart): the folding, the
+    tap-major layout and the 196 -> 224 channel padding are right; an in-place weight edit refreshes them."""
+    bb = loftr.build_backbone(default_cfg).eval()
+    bb.load_state_dict({k[len("backbone."):]: v for k, v in msd.items() if k.startswith("backbone.")}, strict=True)
+    mats, biases = bb._matrices()
+    assert len(mats) == 22 and [m.shape[1] for m in mats[:3]] == [64, 9 * 128, 9 * 128] and mats[6].shape == (196, 9 * 224)
+    assert mats[7].shape == (196, 128) and mats[15].shape == (256, 256) and mats[21].shape == (128, 9 * 224)
+    assert [b is None for b in biases] == [i in (15, 16, 18, 19, 21) for i in range(22)]
+
+    def conv(x, i, cin, k, stride, pad):
+        co = mats[i].shape[0]
+        if cin == 1:
+            w = mats[i][:, :49].reshape(co, 1, 7, 7)
         else:
-            bc, bf = model.backbone(i0)
-            c0, c1 = bc, model.backbone(i1)[0]
-        np.testing.assert_allclose(bc[:1, :, ::2, ::2].numpy(), fx["backbone_c"], **FLOAT_TOL)
-        np.testing.assert_allclose(bf[:1, ::4, ::8, ::8].numpy(), fx["backbone_f"], **FLOAT_TOL)
-        t0 = model.pos_encoding(c0).flatten(2).transpose(1, 2)
-        t1 = model.pos_encoding(c1).flatten(2).transpose(1, 2)
-        t0, t1 = model.loftr_coarse(t0, t1)
-    np.testing.assert_allclose(t0[:, ::8].numpy(), fx["feat_c0"], **FLOAT_TOL)
-    np.testing.assert_allclose(t1[:, ::8].numpy(), fx["feat_c1"], **FLOAT_TOL)
-    np.testing.assert_allclose(t0[0].numpy(), fx["feat_c0_b0"], **FLOAT_TOL)
+            cp = (cin + 31) // 32 * 32
+            w = mats[i].reshape(co, k, k, cp)[:, :, :, :cin].permute(0, 3, 1, 2)
+            assert float(mats[i].reshape(co, k, k, cp)[:, :, :, cin:].abs().max() if cp > cin else 0.0) == 0.0
+        return torch.nn.functional.conv2d(x, w.double(), None if biases[i] is None else biases[i].double(), stride, pad)
 
-
-def test_backbone_refolds_after_weight_load(model, msd):
-    m = Matcher(default_cfg).eval()
-    x = synth.synthetic_gray_pairs(1, 64, 64, seed=3)[0]
+    relu = torch.relu
+    x = synth.synthetic_gray_pairs(1, 64, 96, seed=3)[0].double()
+    h = relu(conv(x, 0, 1, 7, 2, 3))
+    h = relu(h + conv(relu(conv(h, 1, 128, 3, 1, 1)), 2, 128, 3, 1, 1))
+    x1 = relu(h + conv(relu(conv(h, 3, 128, 3, 1, 1)), 4, 128, 3, 1, 1))
+    h = relu(conv(x1, 7, 128, 1, 2, 0) + conv(relu(conv(x1, 5, 128, 3, 2, 1)), 6, 196, 3, 1, 1))
+    x2 = relu(h + conv(relu(conv(h, 8, 196, 3, 1, 1)), 9, 196, 3, 1, 1))
+    h = relu(conv(x2, 12, 196, 1, 2, 0) + conv(relu(conv(x2, 10, 196, 3, 2, 1)), 11, 256, 3, 1, 1))
+    x3 = relu(h + conv(relu(conv(h, 13, 256, 3, 1, 1)), 14, 256, 3, 1, 1))
+    up = lambda t: torch.nn.functional.interpolate(t, scale_factor=2.0, mode="bilinear", align_corners=True)  # noqa: E731
+    lrelu = lambda t: torch.nn.functional.leaky_relu(t, 0.01)  # noqa: E731
+    x3_out = conv(x3, 15, 256, 1, 1, 0)
+    x2_out = conv(lrelu(conv(conv(x2, 16, 196, 1, 1, 0) + up(x3_out), 17, 256, 3, 1, 1)), 18, 256, 3, 1, 1)
+    x1_out = conv(lrelu(conv(conv(x1, 19, 128, 1, 1, 0) + up(x2_out), 20, 196, 3, 1, 1)), 21, 196, 3, 1, 1)
     with torch.no_grad():
-        before = m.backbone(x)[0]
-        m.load_state_dict(msd, strict=True)
-        after = m.backbone(x)[0]
-        want = loftr_ref.resnet_fpn_8_2(msd, x)[0]
-    assert not torch.allclose(before, after)
-    np.testing.assert_allclose(after.numpy(), want.numpy(), **FLOAT_TOL)
+        wc, wf = loftr_ref.resnet_fpn_8_2({k: v.double() for k, v in msd.items()}, x)
+    np.testing.assert_allclose(x3_out.numpy(), wc.numpy(), rtol=0, atol=1e-5)      # fp32 folding vs fp64 reference arithmetic
+    np.testing.assert_allclose(x1_out.numpy(), wf.numpy(), rtol=0, atol=1e-5)
+    # an in-place edit of a BatchNorm statistic changes the cache key (storage address + version counter)
+    k0 = _key(bb)
+    with torch.no_grad():
+        bb.bn1.running_var.mul_(2.0)
+    assert _key(bb) != k0
     with pytest.raises(NotImplementedError):
-        m.train().backbone(x)
+        bb.train()(torch.zeros(1, 1, 16, 16))
 
 
-def test_gather_windows_equals_unfold():
-    g = torch.Generator().manual_seed(0)
-    f = torch.randn(2, 16, 24, 32, generator=g)           # 1/2-res map of a 48x64 image, coarse grid 6x8
-    b = torch.tensor([0, 0, 1, 1, 1])
-    cells = torch.tensor([0, 47, 7, 40, 19])               # corners (zero padding) and an interior cell
-    got = loftr.gather_windows(f, b, cells, 8, 5, 4)
-    u = torch.nn.functional.unfold(f, (5, 5), stride=4, padding=2).view(2, 16, 25, 48).permute(0, 3, 2, 1)
-    assert torch.equal(got, u[b, cells])
+def _key(module):
+    from pope_amd import _lib
+    return _lib.params_key(list(module.parameters()) + list(module.buffers()))
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_fine_stage_vs_fixture(model, msd, golden_dir, name):
-    """FinePreprocess -> loftr_fine -> FineMatching on the fixture's coarse matches (the coarse stage
-    itself is the HIP kernel, tested on the GPU)."""
-    fx = np.load(os.path.join(golden_dir, name + ".npz"))
-    i0, i1 = make_inputs(fx)
+def test_transformer_and_fine_weight_matrices(msd):
+    t = loftr.LocalFeatureTransformer(default_cfg["coarse"]).eval()
+    t.load_state_dict({k[len("loftr_coarse."):]: v for k, v in msd.items() if k.startswith("loftr_coarse.")}, strict=True)
+    layer = t.layers[3]
+    w = layer._weights("f32")
+    assert w is not None and layer._hip["fit"]
+    mats = layer._hip["mats"]
+    assert [tuple(m.shape) for m in mats] == [(256, 256), (512, 256), (256, 256), (512, 512), (256, 512)]
+    assert torch.equal(mats[1][:256], msd["loftr_coarse.layers.3.k_proj.weight"]) and torch.equal(mats[1][256:], msd["loftr_coarse.layers.3.v_proj.weight"])
     with torch.no_grad():
-        ref = loftr_ref.matcher_forward(msd, cfg_with_thr(fx["thr"]), i0, i1)
-        data = {"hw0_i": i0.shape[2:], "hw1_i": i1.shape[2:], "hw0_c": ref["hw0_c"], "hw1_c": ref["hw1_c"],
-                "hw0_f": ref["hw0_f"], "hw1_f": tuple(int(v) for v in fx["hw1_f"])}
-        for k in ("b_ids", "i_ids", "j_ids", "mconf", "mkpts0_c", "mkpts1_c"):
-            data[k] = torch.from_numpy(fx[k])
-        w0, w1 = model.fine_preprocess(ref["feat_f0"], ref["feat_f1"], ref["feat_c0"], ref["feat_c1"], data)
-        assert w0.shape == (len(fx["b_ids"]), 25, 128) and data["W"] == 5
-        w0, w1 = model.loftr_fine(w0, w1)
-        model.fine_matching(w0, w1, data)
-    np.testing.assert_allclose(data["expec_f"].numpy(), fx["expec_f"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(data["mkpts1_f"].numpy(), fx["mkpts1_f"], rtol=0, atol=1e-4)
-    assert np.array_equal(data["mkpts0_f"].numpy(), fx["mkpts0_f"])
-    assert np.abs(fx["mkpts1_f"] - fx["mkpts1_c"]).max() > 0.5     # the refinement actually moves points
+        layer.merge.weight[0, 0] = 1.0e3          # |w| * 256 >= 65504: this layer must take the fp32 path
+    layer._weights("f32")
+    assert not layer._hip["fit"] and layer._weights("f16x3") is None
+    with pytest.raises(NotImplementedError):
+        loftr.LocalFeatureTransformer(dict(default_cfg["coarse"], nhead=4))
+    with pytest.raises(KeyError):
+        loftr.LocalFeatureTransformer(dict(default_cfg["coarse"], layer_names=["self", "other"]))
 
 
 def test_fine_stage_without_matches(model):
@@ -175,9 +179,22 @@ def test_fine_stage_without_matches(model):
     assert data["expec_f"].shape == (0, 3) and data["mkpts0_f"] is data["mkpts0_c"] and data["mkpts1_f"] is data["mkpts1_c"]
 
 
-def test_matcher_refuses_cpu_tensors(model):
-    """No CPU fallback: the coarse matcher is a HIP kernel."""
+def test_no_stage_computes_on_the_cpu(model):
+    """No CPU fallback anywhere in the Matcher: every stage is a HIP call and says so when handed CPU tensors."""
     from pope_amd._lib import PopeHipError
     i0, i1 = synth.synthetic_gray_pairs(1, 64, 64, seed=1)
     with pytest.raises(PopeHipError):
         model({"image0": i0, "image1": i1})
+    with pytest.raises(PopeHipError):
+        model.backbone(i0)
+    with pytest.raises(PopeHipError):
+        model.loftr_coarse(torch.zeros(1, 64, 256), torch.zeros(1, 64, 256))
+    with pytest.raises(PopeHipError):
+        model.loftr_coarse.layers[0](torch.zeros(1, 64, 256), torch.zeros(1, 64, 256))
+    one = torch.zeros(1, dtype=torch.int64)
+    data = {"hw0_i": (64, 64), "hw1_i": (64, 64), "hw0_c": (8, 8), "hw1_c": (8, 8), "hw0_f": (32, 32), "hw1_f": (32, 32),
+            "b_ids": one, "i_ids": one, "j_ids": one, "mconf": torch.ones(1), "mkpts0_c": torch.zeros(1, 2), "mkpts1_c": torch.zeros(1, 2)}
+    with pytest.raises(PopeHipError):
+        model.fine_preprocess(torch.zeros(1, 128, 32, 32), torch.zeros(1, 128, 32, 32), torch.zeros(1, 64, 256), torch.zeros(1, 64, 256), data)
+    with pytest.raises(PopeHipError):
+        model.fine_matching(torch.zeros(1, 25, 128), torch.zeros(1, 25, 128), data)
