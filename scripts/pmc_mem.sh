@@ -10,9 +10,18 @@ for pass in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UT
             "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
             "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_LATENCY_sum TCP_TOTAL_READ_sum" \
             "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
-    # (a fifth pass with the TA_* counters — TA_BUSY_avr, TA_ADDR_STALLED_BY_TC_CYCLES_sum, ... — did not finish on this pool: left out)
+    # Not collected: the TA_* block (TA_BUSY_avr, TA_ADDR_STALLED_BY_TC_CYCLES_sum, ...).  In round 2 a pass with five of them
+    # in ONE run did not finish within the call's limit; that version of this script swallowed the failure and deleted the
+    # pass's log, so its cause (counter replay across the 16 TA instances per shader engine vs. a hung collection) cannot be
+    # read back, and an open-ended counter run is not repeated blind on a shared pool.  What the block would have shown —
+    # the texture-address unit queueing behind L1 misses — is covered from both sides by TCP_PENDING_STALL / TCP_GATE_EN1
+    # and SQ_VMEM_TA_{ADDR,CMD}_FIFO_FULL above.
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmcm_$i -o pmc -- python3 $ROOT/scripts/prof_forward.py 64 2 > $OUT/pmcm_$i.log 2>&1 || echo "pass $i failed"
+    # a pass that fails or overruns its limit fails the script: no summary is written from partial CSVs, and its log stays
+    if ! timeout -k 10 420 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmcm_$i -o pmc -- python3 $ROOT/scripts/prof_forward.py 64 2 > $OUT/pmcm_$i.log 2>&1; then
+        echo "pass $i ($pass) FAILED: see $OUT/pmcm_$i.log; no summary written" | tee -a $OUT/pmc_mem_progress.log
+        exit 1
+    fi
     echo "pass $i done" | tee -a $OUT/pmc_mem_progress.log
 done
 cd $ROOT
