@@ -241,13 +241,16 @@ def gen_vit_archs():
     same eval config as load_dinov2_model) on one 224 x 224 image, seeded synthetic weights with the gamma = O(1)
     recipe; strided rows keep the fixtures small."""
     from dinov2.dinov2.models import vision_transformer as vits
-    for name, ctor, dim, depth in (("vitb_224", vits.vit_base, 768, 12), ("vitl_224", vits.vit_large, 1024, 24)):
+    # vitl_476x630: the shape bench.py's config-5 leg runs (640 x 480 centre crop, 1 531 tokens), one image, every 32nd row
+    for name, ctor, dim, depth, (H, W), stride in (("vitb_224", vits.vit_base, 768, 12, (224, 224), 8),
+                                                   ("vitl_224", vits.vit_large, 1024, 24, (224, 224), 8),
+                                                   ("vitl_476x630", vits.vit_large, 1024, 24, (476, 630), 32)):
         sd = synth.synthetic_state_dict(seed=0, dim=dim, depth=depth)
         model = ctor(patch_size=14, img_size=518, init_values=1e-5, ffn_layer="mlp", block_chunks=0, qkv_bias=True,
                      proj_bias=True, ffn_bias=True)
         model.load_state_dict(sd, strict=True)
         model.eval()
-        x = synth.synthetic_images(1, 224, 224, seed=11)
+        x = synth.synthetic_images(1, H, W, seed=11)
         tap_blocks = (0, depth // 2, depth - 1)
         out, taps = run_ref_vit(model, x, tap_blocks)
         o_taps = {}
@@ -258,9 +261,9 @@ def gen_vit_archs():
         print(name, "oracle-vs-reference max abs diff:", {k: f"{v:.2e}" for k, v in d.items()})
         assert max(d.values()) <= 2e-5, d
         xn = torch.cat([out["x_norm_clstoken"][:, None], out["x_norm_patchtokens"]], 1)
-        rows = torch.arange(0, xn.shape[1], 8)
+        rows = torch.arange(0, xn.shape[1], stride)
         fx = {"weights_seed": 0, "arch": np.array([dim, depth, dim // 64]), "weights_digest": sd_digest(sd), "input_seed": 11,
-              "shape": np.array([1, 224, 224]), "rows": rows.numpy(), "tap_blocks": np.array(tap_blocks),
+              "shape": np.array([1, H, W]), "rows": rows.numpy(), "tap_blocks": np.array(tap_blocks),
               "input_digest": np.array([float(x.double().sum()), float(x.double().abs().sum())]),
               "x_norm": xn[:, rows].numpy(), "x_prenorm": out["x_prenorm"][:, rows].numpy(), "cls": model(x).detach().numpy()}
         for i in tap_blocks:

@@ -35,7 +35,9 @@ constexpr int ROWB = 64;                          // halves per LDS row: 128 B, 
 constexpr int STAGE_H = (RM + RN) * ROWB;          // halves per stage (A rows, then W rows): 64 KB
 constexpr size_t STATS_OFF = size_t(2) * STAGE_H * sizeof(_Float16);
 constexpr size_t CTAB_OFF = STATS_OFF + size_t(2) * 4 * RM * sizeof(float);       // after the two [4][128] row-sum tables
-constexpr size_t RL_LDS_BYTES = CTAB_OFF + size_t(4) * RN * sizeof(float);        // + per-column constants = 141 312 B
+constexpr size_t PF_OFF = CTAB_OFF + size_t(4) * RN * sizeof(float);              // + per-column constants
+constexpr size_t RL_LDS_BYTES = PF_OFF + size_t(8) * 256;                         // + landing pad of the residual prefetch = 143 360 B
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
 constexpr float A_SCALE = K_PLANES_ACT_SCALE, W_SCALE = K_PLANES_W_SCALE;
 
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
@@ -148,6 +150,17 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
                                                                          unsigned(g.M) * unsigned(RN) * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(g.res), 0, unsigned(RES_TABLE ? g.res_mod : g.M) * unsigned(g.ldres) * 4u, 0x00020000);
+
+    // Residual prefetch.  The epilogue's 590 KB per tile (residual in, x and xn out) hit HBM from all 256 CUs at once while
+    // the K loops leave it idle; the residual third of that burst is pulled forward: during the K loop every lane touches
+    // three of the tile's 1 536 residual lines (one dword each, loaded straight into an LDS landing pad that nobody reads —
+    // no register, no wait), so the epilogue's residual loads find their lines in L2 / MALL.
+    lds_void_ptr pf_pad = (lds_void_ptr)(reinterpret_cast<char*>(smem) + PF_OFF + (tid >> 6) * 256);
+    const int pf_step = nk / 3;
+    auto prefetch_res = [&](int tile_, int j) {
+        const unsigned L = unsigned(tid) + 512u * unsigned(j), row = L / 12u, piece = L - 12u * row;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rres, pf_pad, 4, (unsigned(tile_) * RM + row) * unsigned(RN) * 4u + piece * 128u, 0, 0, 0);
+    };
 
     int rl_si = 0;   // stamp index (dev builds)
     auto epilogue = [&](int tile, int free_stage) {
@@ -339,6 +352,8 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
 #ifndef RL_ABL_NOLOAD
             if (ni == 5 && kt + 1 != nk) load_next();
 #endif
+            if constexpr (!RES_TABLE)
+                if (ni == 2 && g.rl_prefetch && pf_step > 0 && kt % pf_step == 0 && kt / pf_step < 3) prefetch_res(tile, kt / pf_step);
 #pragma unroll
             for (int mi = 0; mi < NMI; ++mi) acc[mi][ni] = mfma16(wl[cur], ah[mi], acc[mi][ni]);
 #pragma unroll
@@ -385,7 +400,10 @@ bool pope_gemm_rowln_supported(const GemmParams& g) {
 }
 
 // x = res + gamma * (A.W^T + bias) -> g.C (fp32, may alias res), LayerNorm(x; ln_w, ln_b, ln_eps) -> g.ln_planes or g.ln_f32
-int pope_launch_gemm_rowln(const GemmParams& g, hipStream_t stream) {
+int pope_launch_gemm_rowln(const GemmParams& g_in, hipStream_t stream) {
+    GemmParams g = g_in;
+    static const int prefetch = [] { const char* e = getenv("POPE_RL_PREFETCH"); return e ? atoi(e) : 1; }();   // dev A/B switch
+    g.rl_prefetch = prefetch;
     if (!g.a_pl || !g.w_pl || !g.C || !g.res || !g.ln_w || !g.ln_b || (!g.ln_planes) == (!g.ln_f32) || g.M <= 0) return POPE_ERR_ARG;
     if (!pope_gemm_rowln_supported(g)) return POPE_ERR_ARG;
     if (g.res_mod < 0 || (g.res_mod == 0 && !g.gamma)) return POPE_ERR_ARG;

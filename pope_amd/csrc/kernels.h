@@ -61,6 +61,7 @@ struct GemmParams {
     float ln_eps;
     void* ln_planes;
     float* ln_f32;
+    int rl_prefetch;     // gemm_rowln.hip: touch the tile's residual lines during its K loop (set by the launcher)
     // EPI_CONV (gemm_planes.hip): optional residual as activation planes [M, ldres_pl] (BasicBlock shortcut), activation
     // slope, and — conv_cch > 0 — the implicit 3x3 stride-1 convolution over a zero-bordered NHWC planes tensor
     // [n, Hp, Wp = conv_wp, 32 * conv_cch channels]: output row R = pixel R + Wp + 1, and the A row of K-step
