@@ -20,6 +20,12 @@ namespace {
 
 constexpr int NT = pose::ROUND;
 
+#ifdef POSE_STAMPS   // dev: wall-clock stamps (10 ns ticks) of workgroup 0's phases, returned in E[0] of pair 0 (scripts/pose_time.py)
+#define POSE_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+#else
+#define POSE_STAMP(k) do {} while (0)
+#endif
+
 struct __attribute__((aligned(32))) Pt { double ax, ay, bx, by; };
 
 __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
@@ -29,6 +35,10 @@ __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
     __shared__ unsigned long long s_key;
     __shared__ int s_off, s_ncand, s_good[4];
     const int b = blockIdx.x, tid = threadIdx.x;
+#ifdef POSE_STAMPS
+    __shared__ unsigned long long stamps[8];
+#endif
+    POSE_STAMP(0);
     if (tid == 0) { s_off = 0; s_key = 0ull; s_ncand = 0; }
     __syncthreads();
     {
@@ -101,6 +111,7 @@ __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
                 }
                 ncand = pose::five_point(x0, x1, cand);
             }
+            if (done == 0) POSE_STAMP(1);
             int cnt[10];
             for (int k = 0; k < 10; ++k) cnt[k] = 0;
             for (int base = 0; base < N; base += NT) {
@@ -119,6 +130,7 @@ __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
                     cnt[k] += c;
                 }
             }
+            if (done == 0) POSE_STAMP(2);
             // the first model with the most inliers: (count, lowest hypothesis, lowest root) as one comparable key
             int bk = -1, bc = 0;
             for (int k = 0; k < ncand; ++k)
@@ -155,6 +167,7 @@ __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
         __syncthreads();
     }
 
+    POSE_STAMP(3);
     // metrics.py:86-94: recoverPose for every returned E; the mask is narrowed in place from one E to the next
     const int ncand = s_ncand;
     int best = 0;
@@ -180,6 +193,7 @@ __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
                 if ((bits >> c) & 1u) atomicAdd(&s_good[c], 1);
         }
         __syncthreads();
+        POSE_STAMP(4 + (k ? 1 : 0));
         const int g0 = s_good[0], g1 = s_good[1], g2 = s_good[2], g3 = s_good[3];
         const int ch = (g0 >= g1 && g0 >= g2 && g0 >= g3) ? 0 : (g1 >= g0 && g1 >= g2 && g1 >= g3) ? 1 : (g2 >= g0 && g2 >= g1 && g2 >= g3) ? 2 : 3;
         const int n = ch == 0 ? g0 : ch == 1 ? g1 : ch == 2 ? g2 : g3;
@@ -201,6 +215,11 @@ __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
         }
         __syncthreads();
     }
+#ifdef POSE_STAMPS
+    POSE_STAMP(6);
+    if (blockIdx.x == 0 && tid == 0)
+        for (int j = 0; j < 7; ++j) Eout[j] = double(stamps[j] - stamps[0]) * 0.01;   // microseconds
+#endif
 }
 
 // op-level: one minimal problem per thread (parity tests of the solver itself)

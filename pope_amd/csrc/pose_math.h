@@ -7,9 +7,12 @@
 #include <math.h>
 
 #if defined(__HIPCC__)
-#define POPE_HD __host__ __device__ inline
+#define POPE_HD __host__ __device__ inline __attribute__((always_inline))   // helpers taking array pointers must inline, or the
+                                                                            // arrays they touch are pinned to scratch memory
+#define POPE_UNROLL _Pragma("unroll")   // small fixed loops over thread-private arrays: keeps them in registers (no scratch)
 #else
-#define POPE_HD inline
+#define POPE_HD inline __attribute__((always_inline))
+#define POPE_UNROLL
 #endif
 
 namespace pose {
@@ -253,22 +256,36 @@ POPE_HD int five_point(const double* x0, const double* x1, double (*E_out)[9]) {
             for (int c = 0; c < 3; ++c)
                 for (int k = 0; k < 3; ++k) mac_ql(A[1 + 3 * r + c], lam[3 * r + k], e[3 * k + c], 1.0);
     }
-    // Gauss-Jordan on the ten leading monomials (partial pivoting)
+    // Gauss-Jordan on the ten leading monomials (partial pivoting).  Every index is a compile-time constant after unrolling —
+    // the pivot row is brought up by predicated swaps instead of A[piv][k] — so the matrix is not forced into scratch memory
+    // by a dynamic row index
+    POPE_UNROLL
     for (int c = 0; c < 10; ++c) {
         int piv = c;
         double best = fabs(A[c][c]);
+        POPE_UNROLL
         for (int r = c + 1; r < 10; ++r)
             if (fabs(A[r][c]) > best) { best = fabs(A[r][c]); piv = r; }
         if (!(best > 1e-300)) return 0;
-        if (piv != c)
-            for (int k = c; k < 20; ++k) { const double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
+        POPE_UNROLL
+        for (int r = c + 1; r < 10; ++r) {
+            const bool sw = piv == r;
+            POPE_UNROLL
+            for (int k = c; k < 20; ++k) {
+                const double u = A[c][k], v = A[r][k];
+                A[c][k] = sw ? v : u;
+                A[r][k] = sw ? u : v;
+            }
+        }
         const double inv = 1.0 / A[c][c];
+        POPE_UNROLL
         for (int k = c; k < 20; ++k) A[c][k] *= inv;
+        POPE_UNROLL
         for (int r = 0; r < 10; ++r) {
             if (r == c) continue;
             const double f = A[r][c];
-            if (f != 0.0)
-                for (int k = c; k < 20; ++k) A[r][k] -= f * A[c][k];
+            POPE_UNROLL
+            for (int k = c; k < 20; ++k) A[r][k] -= f * A[c][k];
         }
     }
     // <k> = <e> - z <f>, <l> = <g> - z <h>, <m> = <i> - z <j>:  x bx(z) + y by(z) + b1(z) = 0, coefficients low -> high
@@ -353,9 +370,11 @@ POPE_HD double sampson(const double* E, double ax, double ay, double bx, double 
 
 // the inlier test error <= t2 without the fp64 division (den > 0: a degenerate correspondence is never an inlier)
 POPE_HD bool sampson_inlier(const double* E, double ax, double ay, double bx, double by, double t2) {
-    const double e0 = E[0] * ax + E[1] * ay + E[2], e1 = E[3] * ax + E[4] * ay + E[5], e2 = E[6] * ax + E[7] * ay + E[8];
-    const double t0 = E[0] * bx + E[3] * by + E[6], t1 = E[1] * bx + E[4] * by + E[7];
-    const double num = bx * e0 + by * e1 + e2, den = e0 * e0 + e1 * e1 + t0 * t0 + t1 * t1;
+    // fused multiply-adds spelled out (the library is built with -ffp-contract=off): 18 fp64 instructions per correspondence,
+    // the same on the device and in the host build
+    const double e0 = fma(E[0], ax, fma(E[1], ay, E[2])), e1 = fma(E[3], ax, fma(E[4], ay, E[5])), e2 = fma(E[6], ax, fma(E[7], ay, E[8]));
+    const double t0 = fma(E[0], bx, fma(E[3], by, E[6])), t1 = fma(E[1], bx, fma(E[4], by, E[7]));
+    const double num = fma(bx, e0, fma(by, e1, e2)), den = fma(e0, e0, fma(e1, e1, fma(t0, t0, t1 * t1)));
     return den > 0.0 && num * num <= t2 * den;
 }
 
@@ -377,19 +396,26 @@ POPE_HD int update_num_iters(double conf, double outlier_ratio, int max_iters) {
 // holds the right singular vectors as columns
 template <int N>
 POPE_HD void jacobi_svd(double (*a)[N], double (*v)[N]) {
-    for (int i = 0; i < N; ++i)
+    POPE_UNROLL
+    for (int i = 0; i < N; ++i) {
+        POPE_UNROLL
         for (int j = 0; j < N; ++j) v[i][j] = i == j ? 1.0 : 0.0;
+    }
     for (int sweep = 0; sweep < 30; ++sweep) {
         bool rotated = false;
-        for (int p = 0; p < N - 1; ++p)
+        POPE_UNROLL
+        for (int p = 0; p < N - 1; ++p) {
+            POPE_UNROLL
             for (int q = p + 1; q < N; ++q) {
                 double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                POPE_UNROLL
                 for (int i = 0; i < N; ++i) { alpha += a[i][p] * a[i][p]; beta += a[i][q] * a[i][q]; gamma += a[i][p] * a[i][q]; }
                 if (!(fabs(gamma) > 1e-17 * sqrt(alpha * beta)) || gamma == 0.0) continue;
                 rotated = true;
                 const double zeta = (beta - alpha) / (2.0 * gamma);
                 const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                POPE_UNROLL
                 for (int i = 0; i < N; ++i) {
                     const double ap = a[i][p], aq = a[i][q];
                     a[i][p] = c * ap - s * aq; a[i][q] = s * ap + c * aq;
@@ -397,6 +423,7 @@ POPE_HD void jacobi_svd(double (*a)[N], double (*v)[N]) {
                     v[i][p] = c * vp - s * vq; v[i][q] = s * vp + c * vq;
                 }
             }
+        }
         if (!rotated) break;
     }
 }
@@ -435,25 +462,82 @@ POPE_HD void decompose_essential(const double* E, double* R1, double* R2, double
     t[0] = u3[0]; t[1] = u3[1]; t[2] = u3[2];
 }
 
-// cv::triangulatePoints for one correspondence with P0 = [I | 0], P1 = [R | t] (the right singular vector of the smallest
-// singular value of the 4 x 4 DLT system), then recoverPose's tests: in front of both cameras and closer than `dist`
+// cv::triangulatePoints for one correspondence with P0 = [I | 0], P1 = [R | t]: the right singular vector of the smallest
+// singular value of the 4 x 4 DLT system A, then recoverPose's tests — in front of both cameras and closer than `dist`.
+// The vector is found by inverse iteration on A'A through ONE LU factorisation of A (P A = L U  =>  (A'A)^-1 =
+// U^-1 L^-1 L^-T U^-T: the row permutation cancels): the smallest singular value of a triangulation system lies orders of
+// magnitude below the others for an inlier, so two iterations reach the vector an SVD returns (eight are run: clutter
+// converges slower, and it is never counted anyway) (a vanishing pivot — exact,
+// noise-free data — is replaced by a tiny one, the classical remedy).  ~250 fp64 operations with 4 divisions instead of a
+// 4 x 4 Jacobi SVD's ~9 000 with ~150 square roots and divisions: this was the longest phase of the kernel.
 POPE_HD bool cheirality(const double* R, const double* t, double ax, double ay, double bx, double by, double dist) {
     double a[4][4] = {{-1.0, 0.0, ax, 0.0}, {0.0, -1.0, ay, 0.0},
                       {bx * R[6] - R[0], bx * R[7] - R[1], bx * R[8] - R[2], bx * t[2] - t[0]},
                       {by * R[6] - R[3], by * R[7] - R[4], by * R[8] - R[5], by * t[2] - t[1]}};
-    double v[4][4];
-    jacobi_svd<4>(a, v);
-    int k = 0;
-    double best = 1e300;
-    for (int j = 0; j < 4; ++j) {
-        const double nn = a[0][j] * a[0][j] + a[1][j] * a[1][j] + a[2][j] * a[2][j] + a[3][j] * a[3][j];
-        if (nn < best) { best = nn; k = j; }
+    double amax = 0.0;
+    POPE_UNROLL
+    for (int i = 0; i < 4; ++i) {
+        POPE_UNROLL
+        for (int j = 0; j < 4; ++j) amax = fmax(amax, fabs(a[i][j]));
     }
-    const double X = v[0][k], Y = v[1][k], Z = v[2][k], W = v[3][k];
+    if (!(amax < 1e300)) return false;               // NaN / inf coordinates
+    const double tiny = 1e-30 * amax + 1e-300;
+    double inv[4];
+    POPE_UNROLL
+    for (int k = 0; k < 4; ++k) {
+        int piv = k;
+        double best = fabs(a[k][k]);
+        POPE_UNROLL
+        for (int r = k + 1; r < 4; ++r)
+            if (fabs(a[r][k]) > best) { best = fabs(a[r][k]); piv = r; }
+        POPE_UNROLL
+        for (int r = k + 1; r < 4; ++r)
+            if (piv == r) {
+                POPE_UNROLL
+                for (int c = 0; c < 4; ++c) { const double s = a[k][c]; a[k][c] = a[r][c]; a[r][c] = s; }
+            }
+        double d = a[k][k];
+        if (!(fabs(d) >= tiny)) d = d < 0.0 ? -tiny : tiny;
+        a[k][k] = d;
+        inv[k] = 1.0 / d;
+        POPE_UNROLL
+        for (int r = k + 1; r < 4; ++r) {
+            const double f = a[r][k] * inv[k];
+            a[r][k] = f;
+            POPE_UNROLL
+            for (int c = k + 1; c < 4; ++c) a[r][c] -= f * a[k][c];
+        }
+    }
+    double x[4] = {1.0, 1.0, 1.0, 1.0};
+    for (int it = 0; it < 8; ++it) {   // inliers (the only points recoverPose counts) converge in two; clutter gets the rest
+        // z = U^-T x
+        x[0] *= inv[0];
+        x[1] = (x[1] - a[0][1] * x[0]) * inv[1];
+        x[2] = (x[2] - a[0][2] * x[0] - a[1][2] * x[1]) * inv[2];
+        x[3] = (x[3] - a[0][3] * x[0] - a[1][3] * x[1] - a[2][3] * x[2]) * inv[3];
+        // w = L^-T z (unit upper)
+        x[2] -= a[3][2] * x[3];
+        x[1] -= a[2][1] * x[2] + a[3][1] * x[3];
+        x[0] -= a[1][0] * x[1] + a[2][0] * x[2] + a[3][0] * x[3];
+        // v = L^-1 w (unit lower)
+        x[1] -= a[1][0] * x[0];
+        x[2] -= a[2][0] * x[0] + a[2][1] * x[1];
+        x[3] -= a[3][0] * x[0] + a[3][1] * x[1] + a[3][2] * x[2];
+        // x = U^-1 v
+        x[3] *= inv[3];
+        x[2] = (x[2] - a[2][3] * x[3]) * inv[2];
+        x[1] = (x[1] - a[1][2] * x[2] - a[1][3] * x[3]) * inv[1];
+        x[0] = (x[0] - a[0][1] * x[1] - a[0][2] * x[2] - a[0][3] * x[3]) * inv[0];
+        const double m = fmax(fmax(fabs(x[0]), fabs(x[1])), fmax(fabs(x[2]), fabs(x[3])));
+        if (!(m > 0.0) || !(m < 1e300)) return false;
+        const double s = 1.0 / m;
+        x[0] *= s; x[1] *= s; x[2] *= s; x[3] *= s;
+    }
+    const double X = x[0], Y = x[1], Z = x[2], W = x[3];
     if (!(Z * W > 0.0)) return false;
-    const double x = X / W, y = Y / W, z = Z / W;
-    if (!(z < dist)) return false;
-    const double z1 = R[6] * x + R[7] * y + R[8] * z + t[2];
+    const double px = X / W, py = Y / W, pz = Z / W;
+    if (!(pz < dist)) return false;
+    const double z1 = R[6] * px + R[7] * py + R[8] * pz + t[2];
     return z1 > 0.0 && z1 < dist;
 }
 
