@@ -100,23 +100,54 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
         ctab[2 * RN + tid] = g.ln_w[tid];
         ctab[3 * RN + tid] = g.ln_b[tid];
     }
-    u32x4 r0[NLD];  // A rows, then W rows: the K-step after the one in the other LDS stage
-    int ld_ord = 0, ord = 0;
-    int ld_tile = first, ld_kt = 0;
     // one VGPR offset per operand: the row block (64 i rows), the tile and the K-step travel in the scalar offset
     const unsigned va = unsigned(prow) * unsigned(g.lda) * 4u + pc * 16u, vw = unsigned(prow) * unsigned(g.ldw) * 4u + pc * 16u;
     const unsigned a64 = 64u * unsigned(g.lda) * 4u, w64 = 64u * unsigned(g.ldw) * 4u;
+    u32x4 r0[NLD];  // A rows, then W rows: the K-step after the one in the other LDS stage
+#ifdef RL_DMA_W   // dev experiment: the W rows (6 of the 8 pieces) through LDS-direct loads, A on the register path
+    int w_kt = 0;
+    const unsigned vw_sw = unsigned(prow) * unsigned(g.ldw) * 4u + unsigned(pc ^ (prow & 7)) * 16u;
+    auto dma_w = [&](int stage) {
+        _Float16* S = lds + stage * STAGE_H + (RM + 8 * wave) * ROWB;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_ptr)(S + 64 * i * ROWB), 16, vw_sw, unsigned(w_kt) * 128u + i * w64, 0, 0);
+        w_kt = pope_uniform_select(++w_kt == nk, 0, w_kt);
+    };
+#endif
+#ifdef RL_DMA_A
+    // Mixed staging: the A rows (2 of the 8 pieces per thread and K-step) go straight into LDS (buffer_load ... lds: no
+    // register, no ds_write), the W rows keep the register path.  A wave's 64 lanes fill 1 KB of contiguous LDS = eight
+    // 128-byte rows; the 16-byte chunk swizzle (chunk c of row r at position c ^ (r & 7)) is applied on the SOURCE side:
+    // the lane at position p of row r fetches chunk p ^ (r & 7).
+    int a_ord = 0, a_tile = first, a_kt = 0;
+    const unsigned va_sw = unsigned(prow) * unsigned(g.lda) * 4u + unsigned(pc ^ (prow & 7)) * 16u;
+    auto dma_a = [&](int stage) {
+        const int lt = a_tile < n_tiles ? a_tile : n_tiles - 1;
+        const unsigned sa = unsigned(lt) * unsigned(RM) * unsigned(g.lda) * 4u + unsigned(a_kt) * 128u;
+        _Float16* S = lds + stage * STAGE_H + (8 * wave) * ROWB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(S + 64 * i * ROWB), 16, va_sw, sa + i * a64, 0, 3);
+        const int wrap = ++a_kt == nk;
+        a_kt = pope_uniform_select(wrap, 0, a_kt);
+        a_ord += wrap;
+        a_tile = tile_of(a_ord);
+    };
+#endif
+    int ld_ord = 0, ord = 0;
+    int ld_tile = first, ld_kt = 0;
     auto load_next = [&]() {
         const int lt = ld_tile < n_tiles ? ld_tile : n_tiles - 1;   // past the end: re-load, never consumed
         const unsigned sa = unsigned(lt) * unsigned(RM) * unsigned(g.lda) * 4u + unsigned(ld_kt) * 128u, sw = unsigned(ld_kt) * 128u;
         // A rows are read exactly once per launch (a tile spans all 384 columns): sc0 + nt keeps the 150 - 600 MB stream
         // from displacing x / xn, which the next kernels re-read (+0.8 % on the step; the same hint on the residual
         // loads, the x stores or the xn stores costs 1 - 10 %: measured, left at the default policy)
-#ifndef RL_ABL_NOLOAD_A   // dev ablations (wrong results; scripts/ab_rowln.sh): which operand's loads cost the K-step what
+#if !defined(RL_ABL_NOLOAD_A) && !defined(RL_DMA_A)   // dev ablations (wrong results; scripts/ab_rowln.sh): which operand's loads cost the K-step what
 #pragma unroll
         for (int i = 0; i < 2; ++i) r0[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, sa + i * a64, 3);
 #endif
-#ifndef RL_ABL_NOLOAD_W
+#if !defined(RL_ABL_NOLOAD_W) && !defined(RL_DMA_W)
 #pragma unroll
         for (int i = 0; i < 6; ++i) r0[2 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, sw + i * w64, 0);
 #endif
@@ -129,10 +160,14 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
     const int wr_off = prow * ROWB + 8 * (pc ^ (prow & 7));   // rows prow + 64 i: same r & 7
     auto write_stage = [&](int s) {
         _Float16* S = lds + s * STAGE_H + wr_off;
+#ifndef RL_DMA_A
 #pragma unroll
         for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(S + 64 * i * ROWB) = r0[i];
+#endif
+#ifndef RL_DMA_W
 #pragma unroll
         for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(S + (RM + 64 * i) * ROWB) = r0[2 + i];
+#endif
     };
     // fragment t: rows 16 t + l15 of this wave's rows, logical chunk plane * 4 + q4
     const int sw_hi = 8 * (q4 ^ (l15 & 7)), sw_lo = 8 * ((4 + q4) ^ (l15 & 7));
@@ -300,6 +335,12 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
     };
 
     // prologue: item 0 -> LDS stage 0; item 1 in flight
+#ifdef RL_DMA_A
+    dma_a(0);
+#endif
+#ifdef RL_DMA_W
+    dma_w(0);
+#endif
     load_next();
     write_stage(0);
     load_next();
@@ -310,6 +351,12 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
 
     auto item = [&](int s) {
         const _Float16* S = lds + (s & 1) * STAGE_H;
+#ifdef RL_DMA_A
+        dma_a((s + 1) & 1);   // the A rows of item s + 1 into the stage nobody reads during this K-step
+#endif
+#ifdef RL_DMA_W
+        dma_w((s + 1) & 1);
+#endif
         // ni-major: the A fragments (hi, lo: 8 x 4 registers) stay for the K-step, the W fragments stream through two at
         // a time (lo, hi of column block ni), each feeding 12 MFMAs — 48 fragment registers instead of 80 (the kernel
         // sits at the 256-register line: 96 accumulators + 32 staging).  Per accumulator the order of the partial
