@@ -222,8 +222,29 @@ def pose_leg(pipe, img0, img1, device, steps=3, cpu_baseline=True):
         res = estimate_pose_batch(out["mkpts0_c"], out["mkpts1_c"], out["counts"], K, K, 0.5, 0.99)
         return out, res
 
+    # the same with the solver on a side stream: one workgroup per pair fills half the chip for 2.4 ms of latency-bound fp64
+    # work, so it is queued behind the matcher (an event) and runs under the NEXT step's extraction kernels
+    side = torch.cuda.Stream(device)
+    pending = []
+
+    def step_overlapped():
+        out = pipe(img0, img1)
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            res = estimate_pose_batch(out["mkpts0_c"], out["mkpts1_c"], out["counts"], K, K, 0.5, 0.99)
+            for t in (out["mkpts0_c"], out["mkpts1_c"]):
+                t.record_stream(side)
+        pending.append(res)
+        return out, res
+
     step()
     ms, (out, res) = _wall_ms(step, steps)
+    step_overlapped()
+    ms_o, (out_o, res_o) = _wall_ms(step_overlapped, steps)
+    torch.cuda.synchronize()
+    same = all(torch.equal(res_o[k], res[k]) for k in ("R", "t", "inliers", "info"))
     k_ms, _ = _events_ms(lambda: estimate_pose_batch(out["mkpts0_c"], out["mkpts1_c"], out["counts"], K, K, 0.5, 0.99), 5)
     info = res["info"].cpu().numpy()
     n = img0.shape[0]
@@ -239,6 +260,8 @@ def pose_leg(pipe, img0, img1, device, steps=3, cpu_baseline=True):
     r = {"value": round(n * 1e3 / ms, 1), "unit": "image-pairs/s", "ms_per_step": round(ms, 3), "steps": steps,
          "workload": f"the headline step ({n} pairs: extract + dense match) followed by estimate_pose(mkpts0_c, mkpts1_c, K, K, 0.5, 0.99) for "
                      "every pair in one launch (five-point RANSAC + recoverPose, fp64)",
+         "overlapped": {"value": round(n * 1e3 / ms_o, 1), "ms_per_step": round(ms_o, 3), "same_results": bool(same),
+                        "note": "pose on a side HIP stream behind the matcher's event: it runs under the next step's extraction"},
          "pose_kernel_ms": round(k_ms, 3), "pose_kernel_pairs_per_s": round(n * 1e3 / k_ms, 1),
          "matches_per_pair_mean": round(float(info[:, 6].mean()), 1), "hypotheses_per_pair_mean": round(float(info[:, 2].mean()), 1),
          "ransac_inliers_per_pair_mean": round(float(info[:, 1].mean()), 1), "poses_found": int((info[:, 0] > 0).sum()), "verified": not bad}

@@ -127,7 +127,7 @@ def test_vote_top3_matches_reference_loop(model, sd0):
     assert list(idx) == list(want_idx) and 4 in idx
 
 
-@pytest.mark.parametrize("name", ["vit_224", "vit_476x630", "vitb_224", "vitl_224"])
+@pytest.mark.parametrize("name", ["vit_224", "vit_476x630", "vitb_224", "vitl_224", "vitl_476x630"])
 def test_f16_precision_mode(hip_lib, golden_dir, sd0, name):
     """precision = "f16" (opt-in; BASELINE config 5's dtype): plain f16 operands, one MFMA per product in every block's
     Linear layers and attention, fp32 accumulation / residual stream / softmax / LayerNorm.  Against the fp32 reference
@@ -164,11 +164,12 @@ def test_f16_precision_mode(hip_lib, golden_dir, sd0, name):
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "f32"])
-@pytest.mark.parametrize("name", ["vitb_224", "vitl_224"])
+@pytest.mark.parametrize("name", ["vitb_224", "vitl_224", "vitl_476x630"])
 def test_vit_base_and_large_match_reference_fixture(hip_lib, golden_dir, name, prec):
     """BASELINE config 5, DINOv2 half: the ViT-B/14 (768-d, 12 heads) and ViT-L/14 (1024-d, 16 heads, 24 blocks)
     backbones of the reference (vision_transformer.py:319-342) through the same kernels — fixtures generated by the
-    reference's own vit_base / vit_large (oracle/gen_golden.py:gen_vit_archs)."""
+    reference's own vit_base / vit_large (oracle/gen_golden.py:gen_vit_archs); `vitl_476x630` is the shape bench.py's config-5
+    leg runs (640 x 480 centre crop, 1 531 tokens)."""
     from pope_amd import dinov2, synth
     fx = np.load(os.path.join(golden_dir, name + ".npz"))
     dim, depth, heads = (int(v) for v in fx["arch"])
