@@ -397,6 +397,11 @@ def main():
                 pipe.want_conf = False
                 torch.cuda.empty_cache()
             try:
+                result["attention_ramp"] = bench_legs.attention_ramp_leg(device, chunk=args.chunk)
+            except Exception as e:  # noqa: BLE001
+                result["attention_ramp"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+            try:
                 vit, matcher = bench_legs.build_models(device)
                 result["loftr_matcher"] = {"pairs_3": bench_legs.loftr_matcher_leg(matcher, device, 3, cpu_baseline=cpu),
                                            "pairs_24": bench_legs.loftr_matcher_leg(matcher, device, 24)}

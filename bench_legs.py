@@ -278,3 +278,40 @@ def pose_leg(pipe, img0, img1, device, steps=3, cpu_baseline=True):
                              "sample": f"pair 0 of the batch ({len(a)} matches, {oi.get('hypotheses')} hypotheses) through oracle/pose_ref.py "
                                        f"(numpy fp64, scalar loops); inlier mask identical to the GPU's: {same}"}
     return r
+
+
+def attention_ramp_leg(device, chunk=64, ntok=1531, heads=6, iters=10):
+    """Data dependence of the dominant kernel, made visible: the lazy-softmax attention redoes a 64-key tile exactly when its
+    probabilities leave the f16 range of the running reference (attention_f16x3.hip).  On the bench's synthetic weights that
+    happens on tile 0 only; real checkpoints (sink tokens, outlier channels) may sit anywhere on the curve below, which times
+    the kernel (planes in / planes out, the bench shape) on scores that CLIMB by `ramp` log2 units per 64-key tile."""
+    import ctypes as C
+    from pope_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator(device=device).manual_seed(0)
+    out = {"shape": [chunk, ntok, heads, 64], "unit": "ms per launch", "launches_timed": iters, "ramps_log2_units_per_tile": {}}
+    pout = torch.empty(chunk * ntok, heads * 2, 2, 32, dtype=torch.float16, device=device)
+    st = _lib.stream_of(device)
+    fl = 4.0 * chunk * ntok * ntok * heads * 64
+    for ramp in (0.0, 1.0, 2.9, 6.5, 13.0):
+        qkv = torch.randn(chunk, ntok, 3, heads, 64, device=device, generator=g)
+        if ramp > 0:
+            qkv.mul_(0.3)
+            u = torch.randn(heads, 64, device=device, generator=g)
+            u = u / u.norm(dim=-1, keepdim=True) * 8.0
+            qkv[:, :, 0] += u
+            qkv[:, :, 1] += u * (torch.arange(ntok, device=device, dtype=torch.float32) / 64.0 * (ramp / 8.0))[None, :, None, None]
+        pin = _lib.to_planes(qkv.reshape(chunk * ntok, -1), _lib.PLANES_ACT_SCALE)
+        del qkv
+        call = lambda: _lib.check(lib.pope_attention_planes_f32(C.c_void_p(pin.data_ptr()), C.c_void_p(pout.data_ptr()), chunk, ntok, heads, st),  # noqa: E731
+                                  "pope_attention_planes_f32")
+        for _ in range(3):
+            call()
+        ms, _ = _events_ms(call, iters)
+        out["ramps_log2_units_per_tile"][str(ramp)] = {"ms": round(ms, 4), "frac_of_f16_peak": round(fl / ms / 1e9 / PEAK_F16_MFMA_TFLOPS, 4),
+                                                       "finite": bool(torch.isfinite(pout.float()).all())}
+        del pin
+    out["note"] = ("ramp 0 = unstructured random scores (exact pass on the first tile only, like the bench's weights); 2.9 / 6.5 / 13 force "
+                   "the exact pass on about every 2nd / every / every tile; results do not depend on the path taken "
+                   "(tests/test_gpu_ops.py::test_attention_lazy_reference_paths)")
+    return out

@@ -184,3 +184,29 @@ def test_straight_from_the_dense_matcher(dev, sd0):
         assert (ret is None) == (info[b, 0] == 0)
         if ret is not None:
             assert np.array_equal(res["inliers"].cpu().numpy()[sel], ret[2])
+
+
+def test_degenerate_inputs_terminate_with_none(dev):
+    """Identical points, NaN / inf coordinates, a singular K: every loop of the solver is bounded, the pair reports `None`
+    (or a pose with a handful of inliers) and the pairs next to it in the batch are untouched."""
+    from pope_amd import pose, synth
+    good = synth.synthetic_pose_scene(80, 1, outlier=0.2, noise=0.0)
+    same = (np.full((50, 2), 100.0, np.float32), np.full((50, 2), 60.0, np.float32), good[2], good[3])
+    nan = (np.full((40, 2), np.nan, np.float32), np.full((40, 2), np.nan, np.float32), good[2], good[3])
+    g = np.random.default_rng(0)
+    huge = ((g.uniform(-1, 1, (30, 2)) * 3.0e38).astype(np.float32), (g.uniform(-1, 1, (30, 2)) * 3.0e38).astype(np.float32), good[2], good[3])
+    k0 = torch.from_numpy(np.concatenate([good[0], same[0], nan[0], huge[0], good[0]])).to(dev)
+    k1 = torch.from_numpy(np.concatenate([good[1], same[1], nan[1], huge[1], good[1]])).to(dev)
+    counts = torch.tensor([80, 50, 40, 30, 80], dtype=torch.int32)
+    out = pose.estimate_pose_batch(k0, k1, counts, good[2], good[3], 0.05, 0.99)
+    torch.cuda.synchronize()
+    info = out["info"].cpu().numpy()
+    assert info[0, 0] > 0 and np.array_equal(info[0], info[4])                # the good pair, twice: identical, unaffected
+    assert torch.equal(out["R"][0], out["R"][4]) and bool(torch.isfinite(out["R"][0]).all())
+    assert info[2, 0] == 0 and info[2, 1] == 0                                # NaN points: no model, None
+    assert info[1, 0] <= 50 and info[3, 0] <= 30 and np.all(info[:, 7] == 0)  # degenerate geometry: whatever it is, it ended
+    # a singular camera matrix (fx = 0): coordinates become inf / NaN -> None, not a hang
+    Kbad = good[2].copy()
+    Kbad[0, 0] = 0.0
+    res = pose.estimate_pose_batch(k0[:80], k1[:80], counts[:1], Kbad, good[3], 0.5, 0.99)
+    assert int(res["n_inliers"][0]) == 0
