@@ -278,7 +278,15 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
     static const bool no_rowln = getenv("POPE_NO_ROWLN") && atoi(getenv("POPE_NO_ROWLN"));
     GemmParams probe = {};
     probe.M = rows; probe.N = dim; probe.K = dim; probe.lda = dim; probe.ldw = dim; probe.ldc = dim; probe.ldres = dim;
-    const bool fused = planes && !plain && w->patch_wp && !no_rowln && pope_gemm_rowln_supported(probe);
+    const bool fusable = planes && !plain && w->patch_wp && !no_rowln && pope_gemm_rowln_supported(probe);
+    // Small batches: the full-row-tile kernel has one tile per 128 rows, each a serial chain of K / 32 K-steps + a 23 us
+    // epilogue; while the 128 x 128 residual GEMM still fits ONE round of its 2 x CUs workgroup slots (3 column tiles per row
+    // tile) it finishes sooner, and `layernorm_rowln_order` reproduces the fused epilogue's LayerNorm bit for bit — an image
+    // gives the same tokens alone (this path) and inside a 64-image chunk (fused path).  Driver step (9 images of 196 x
+    // 196): proj 38 -> ~25 us, FC2 105 -> ~70 us per launch.
+    static const bool no_small = getenv("POPE_ROWLN_ALWAYS") && atoi(getenv("POPE_ROWLN_ALWAYS"));   // dev A/B switch
+    const bool small = fusable && !no_small && 3 * ((rows + 127) / 128) <= 2 * pope_cu_count();
+    const bool fused = fusable && !small;
     // plain GEMM over the token rows: C (fp32) or c_f16 (f16 row-major) = epi(a_f16 . w_f16^T + bias [...])
     auto plain_gemm = [&](const void* a_f16, const void* w_f16, const float* bias, float* Cf, void* c_f16, int N, int K, int epi,
                           const float* gamma, const float* res) {
@@ -344,7 +352,8 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
         }
         if (!fused) {
             POPE_MARK(POPE_K_LAYERNORM);
-            if (planes) POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm1_w, k.norm1_b, xn_pl, rows, dim, eps, range_flag, stream));
+            if (small) POPE_TRY(pope_launch_layernorm_rowln_order(x, k.norm1_w, k.norm1_b, xn_pl, nullptr, rows, eps, range_flag, stream));
+            else if (planes) POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm1_w, k.norm1_b, xn_pl, rows, dim, eps, range_flag, stream));
             else POPE_TRY(pope_launch_layernorm_f32(x, dim, k.norm1_w, k.norm1_b, xn, dim, rows, dim, eps, stream));
         }
         POPE_MARK(POPE_K_GEMM_QKV);
@@ -364,7 +373,8 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
         // x = x + ls2(mlp(norm2(x)))                                       block.py:106
         if (!fused) {
             POPE_MARK(POPE_K_LAYERNORM);
-            if (planes) POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm2_w, k.norm2_b, xn_pl, rows, dim, eps, range_flag, stream));
+            if (small) POPE_TRY(pope_launch_layernorm_rowln_order(x, k.norm2_w, k.norm2_b, xn_pl, nullptr, rows, eps, range_flag, stream));
+            else if (planes) POPE_TRY(pope_launch_layernorm_planes(x, dim, k.norm2_w, k.norm2_b, xn_pl, rows, dim, eps, range_flag, stream));
             else POPE_TRY(pope_launch_layernorm_f32(x, dim, k.norm2_w, k.norm2_b, xn, dim, rows, dim, eps, stream));
         }
         POPE_MARK(POPE_K_GEMM_FC1);
@@ -394,7 +404,8 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
     }
     if (x_norm && !fused) {
         POPE_MARK(POPE_K_LAYERNORM);
-        POPE_TRY(pope_launch_layernorm_f32(x, dim, w->norm_w, w->norm_b, x_norm, dim, rows, dim, eps, stream));
+        if (small) POPE_TRY(pope_launch_layernorm_rowln_order(x, w->norm_w, w->norm_b, nullptr, x_norm, rows, eps, nullptr, stream));
+        else POPE_TRY(pope_launch_layernorm_f32(x, dim, w->norm_w, w->norm_b, x_norm, dim, rows, dim, eps, stream));
     }
     POPE_MARK(-1);  // closing event
 #undef POPE_TRY

@@ -106,6 +106,9 @@ constexpr float K_PLANES_ACT_SCALE = 8.0f, K_PLANES_W_SCALE = 256.0f;  // == POP
 // y = LayerNorm(x) written as f16 planes (scale POPE_PLANES_ACT_SCALE), [rows, dim] halves each.
 int pope_launch_layernorm_planes(const float* x, int ldx, const float* w, const float* b, void* y_pl,
                                  int rows, int dim, float eps, unsigned* range_flag, hipStream_t stream);
+// LayerNorm(384) in the exact arithmetic of gemm_rowln.hip's fused epilogue (bit-identical results): the small-batch twin
+int pope_launch_layernorm_rowln_order(const float* x, const float* w, const float* b, void* y_planes, float* y_f32, int rows, float eps,
+                                      unsigned* flag, hipStream_t stream);
 // Generic fp32 [rows, ld] -> planes converter (ld % 32 == 0).
 // patch embed, f16x3: image [B,3,H,W] -> A planes [B*ntok, kp] (kp = 3*patch^2 rounded up to 32; row b*ntok is the
 // all-zero CLS row, row b*ntok + 1 + n the flattened patch n; zero K padding)

@@ -238,6 +238,69 @@ __global__ __launch_bounds__(256) void range_check_kernel(const float* __restric
     pope_range_flag(flag, bit, nonfinite || !(amax < POPE_F16_OVERFLOW));
 }
 
+
+// LayerNorm over 384 columns in EXACTLY the arithmetic of gemm_rowln.hip's fused epilogue — same association of every sum:
+// per 16-lane row group, lane (wn, q4) adds its six column quads ((a0 + a1) + (a2 + a3)) in ascending order, the four q4
+// lanes of a column wave combine as (s0 + s1) + (s2 + s3), the four column waves the same way; mean first, then the centred
+// second moment; y = ((x - mean) * rstd) * w + b — so that a small batch, which runs the 128 x 128 residual GEMM + this kernel
+// (the full-row-tile kernel cannot fill the chip below ~170 row tiles and serialises 12 / 48 K-steps per tile), returns
+// bit for bit what the same image returns inside a large batch on the fused kernel.  16 rows per 256-thread block.
+template <bool PLANES>
+__global__ __launch_bounds__(256) void layernorm_rowln_order_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ b, void* __restrict__ out, int rows,
+                                                                    float eps, unsigned* flag) {
+    constexpr int RN = 384;
+    const int j = threadIdx.x & 15, wn = j >> 2, q4 = j & 3;
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool ok = row < rows;
+    const int col0 = wn * 96 + 4 * q4;
+    f32x4 v[6];
+    float s = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+        v[ni] = ok ? *reinterpret_cast<const f32x4*>(x + size_t(row) * RN + col0 + 16 * ni) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[ni][0] + v[ni][1]) + (v[ni][2] + v[ni][3]);
+    }
+    auto tree = [](float t) {   // q4 pairs, q4 halves, wave pairs, wave halves: commutative adds, fixed association
+        t = t + __shfl_xor(t, 1);
+        t = t + __shfl_xor(t, 2);
+        t = t + __shfl_xor(t, 4);
+        t = t + __shfl_xor(t, 8);
+        return t;
+    };
+    const float mean = tree(s) * (1.0f / float(RN));
+    float qs = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+        const f32x4 d = v[ni] - mean;
+        v[ni] = d;
+        qs += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+    const float var = tree(qs) * (1.0f / float(RN));
+    const float rstd = 1.0f / sqrtf(var + eps);
+    f32x2 amax = {0.f, 0.f};
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+        const int c = col0 + 16 * ni;
+        const f32x4 lw = *reinterpret_cast<const f32x4*>(w + c), lb = *reinterpret_cast<const f32x4*>(b + c);
+        const f32x4 y = v[ni] * rstd * lw + lb;
+        if (!ok) continue;
+        if constexpr (PLANES) {
+            const f32x4 ys = y * K_PLANES_ACT_SCALE;
+            pope_amax4x2(amax, ys);
+            pope_f16x4 hi, lo;
+            pope_split4(ys, hi, lo);
+            _Float16* hp = static_cast<_Float16*>(out) + size_t(row) * 2 * RN + (c >> 5) * 64 + (c & 31);
+            *reinterpret_cast<pope_f16x4*>(hp) = hi;
+            *reinterpret_cast<pope_f16x4*>(hp + 32) = lo;
+        } else {
+            *reinterpret_cast<f32x4*>(static_cast<float*>(out) + size_t(row) * RN + c) = y;
+        }
+    }
+    if constexpr (PLANES)
+        pope_range_flag(flag, POPE_RANGE_LAYERNORM,
+                        ok && (!(__builtin_fmaxf(amax[0], amax[1]) < POPE_F16_OVERFLOW) || !(__builtin_fabsf(mean) + rstd < INFINITY)));
+}
 }  // namespace
 
 int pope_launch_range_check(const float* x, size_t n, float scale, unsigned* flag, unsigned bit, hipStream_t stream) {
@@ -320,5 +383,14 @@ int pope_launch_layernorm_f32(const float* x, int ldx, const float* w, const flo
         default: return POPE_ERR_ARG;
     }
 #undef POPE_LN_CASE
+    return pope_check_launch();
+}
+
+int pope_launch_layernorm_rowln_order(const float* x, const float* w, const float* b, void* y_planes, float* y_f32, int rows, float eps,
+                                      unsigned* flag, hipStream_t stream) {
+    if (!x || !w || !b || (!y_planes) == (!y_f32) || rows <= 0) return POPE_ERR_ARG;
+    const dim3 grid((rows + 15) / 16), block(256);
+    if (y_planes) hipLaunchKernelGGL(layernorm_rowln_order_kernel<true>, grid, block, 0, stream, x, w, b, y_planes, rows, eps, flag);
+    else hipLaunchKernelGGL(layernorm_rowln_order_kernel<false>, grid, block, 0, stream, x, w, b, static_cast<void*>(y_f32), rows, eps, flag);
     return pope_check_launch();
 }

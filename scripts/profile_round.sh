@@ -11,7 +11,7 @@ cd /tmp
 # (a) the default command as the driver runs it (self-check launches and the strict-fp32 leg included), (b) the f16x3 step
 # alone: per-kernel averages that can be compared with the line's HIP-event figures
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_default -o bench -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_profiled_default.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strict-f32 --no-verify > $OUT/bench_profiled.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strict-f32 --no-verify --no-legs --no-config5 > $OUT/bench_profiled.json
 # the secondary legs on their own (bench_legs.py): the LoFTR Matcher at 3 and 24 pairs, and one query of the drivers' loop
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_loftr -o loftr -- python3 $ROOT/bench.py --only loftr_matcher > $OUT/bench_loftr_matcher.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_driver -o driver -- python3 $ROOT/bench.py --only driver_step > $OUT/bench_driver_step.json
