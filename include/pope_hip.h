@@ -315,7 +315,9 @@ typedef struct pope_sam_encoder_weights {
     int img, patch, dim, depth, heads, hidden, out_chans, window;
     int precision;   /* POPE_PREC_F16X3, or POPE_PREC_F16: BASELINE config 5's "fp16" — every `*_wp` is then a plain f16
                       * row-major matrix (value * 256) and every contraction ONE f16 MFMA per product with fp32
-                      * accumulation; residual stream, softmax, LayerNorm statistics and GELU stay fp32 */
+                      * accumulation; residual stream, softmax, LayerNorm statistics and GELU stay fp32 —, or
+                      * POPE_PREC_F32_MFMA: every `*_wp` is a plain fp32 matrix and every contraction runs on the fp32 MFMA (the
+                      * reference's arithmetic, no range contract: what a range-guard event is re-run in; ~10x slower) */
     const void* patch_wp; const float* patch_b;
     const float* pos;
     const float* ones;

@@ -264,7 +264,8 @@ struct SamEncParams {
     const float* image;   // [B, 3, img, img] fp32
     float* out;           // [B, out_chans, g, g] fp32, g = img / patch
     int B, img, patch, dim, depth, heads, hidden, out_chans, window;
-    int precision;        // POPE_PREC_F16X3 (weights = planes) | POPE_PREC_F16 (weights = f16 row-major, value * 256)
+    int precision;        // POPE_PREC_F16X3 (weights = planes) | POPE_PREC_F16 (weights = f16 row-major, value * 256) |
+                          // POPE_PREC_F32_MFMA (weights = fp32 matrices: the range guard's re-run, sam_f32.hip)
     float block_eps, neck_eps;   // LayerNorm eps of the blocks / of the neck's LayerNorm2d (<= 0: 1e-6)
     const void* patch_wp; const float* patch_b;   // [dim, 3 patch^2], [dim]
     const float* pos;                             // [g g, dim] or null (use_abs_pos = False)
@@ -280,6 +281,9 @@ struct SamEncParams {
 };
 size_t pope_sam_encoder_workspace(const SamEncParams& q);
 int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream);
+// POPE_PREC_F32_MFMA twin (sam_f32.hip): every `*_wp` is a plain fp32 [out, in] matrix; same workspace; arguments validated by
+// pope_launch_sam_encoder, which dispatches here
+int pope_launch_sam_encoder_f32mfma(const SamEncParams& q, hipStream_t stream);
 
 // Batched relative pose (pose.hip; src/utils/metrics.py:69-94): one workgroup per pair
 struct PoseParams {

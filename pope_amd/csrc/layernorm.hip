@@ -378,8 +378,8 @@ int pope_launch_layernorm_f32(const float* x, int ldx, const float* w, const flo
         hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, stream, x, ldx, w, b, y, ldy, rows, eps); \
         break;
     switch (dim / 128) {
-        POPE_LN_CASE(1) POPE_LN_CASE(2) POPE_LN_CASE(3) POPE_LN_CASE(4) POPE_LN_CASE(6) POPE_LN_CASE(8)
-        POPE_LN_CASE(12) POPE_LN_CASE(16)
+        POPE_LN_CASE(1) POPE_LN_CASE(2) POPE_LN_CASE(3) POPE_LN_CASE(4) POPE_LN_CASE(5) POPE_LN_CASE(6) POPE_LN_CASE(8)
+        POPE_LN_CASE(10) POPE_LN_CASE(12) POPE_LN_CASE(16)   // 5, 10: the SAM ViT-H width 1280 and its test twin 640
         default: return POPE_ERR_ARG;
     }
 #undef POPE_LN_CASE

@@ -740,6 +740,7 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
     unsigned* flag = q.range_flag;
     // precision "f16" (POPE_PREC_F16): every operand is a plain f16 tensor (activations * 8, weights * 256), one MFMA per
     // product, fp32 accumulation, fp32 residual stream / softmax / LayerNorm statistics — BASELINE config 5's dtype
+    if (q.precision == POPE_PREC_F32_MFMA) return pope_launch_sam_encoder_f32mfma(q, stream);   // sam_f32.hip: `*_wp` are fp32 matrices
     if (q.precision != POPE_PREC_F16X3 && q.precision != POPE_PREC_F16) return POPE_ERR_ARG;
     const bool plain = q.precision == POPE_PREC_F16;
     if (plain && ((dim & 63) || (hidden & 63) || (kp & 63))) return POPE_ERR_ARG;

@@ -129,8 +129,10 @@ class ImageEncoderViT(nn.Module):
         # "f16x3" (default): fp32 operands as hi + lo f16, three MFMAs per product — fp32-level results (1e-5 from the
         # reference).  "f16": BASELINE config 5's dtype — plain f16 operands, ONE MFMA per product, fp32 accumulation and an
         # fp32 residual stream / softmax / LayerNorm; results at f16 level (a few 1e-3 from the fp32 reference).
+        # "f32": every contraction on the fp32 MFMA (sam_f32.hip) — the reference's arithmetic, no range contract, ~10x slower:
+        # what a range-guard event of the other two modes is re-run in.
         self.precision = "f16x3"
-        self.on_overflow = "raise"     # the encoder has no fp32-MFMA twin: leaving the f16 range is an error
+        self.on_overflow = "rerun_f32"  # f16x3 / f16 range guard: "rerun_f32" (warn, run the call again on the fp32 MFMA) | "raise"
         self.overflow_events = 0
         self.max_batch = 8             # images per launch sequence (32-bit offsets of the GEMMs: 4096 x 5120 x 4 B x B)
         self._wcache = {}
@@ -153,12 +155,13 @@ class ImageEncoderViT(nn.Module):
             self._src = list(self.parameters())
         return self._src
 
-    def _weights(self):
-        if self.precision not in ("f16x3", "f16"):
-            raise ValueError(f"ImageEncoderViT.precision must be 'f16x3' or 'f16', not {self.precision!r}")
-        plain = self.precision == "f16"
+    def _weights(self, precision=None):
+        precision = precision or self.precision
+        if precision not in ("f16x3", "f16", "f32"):
+            raise ValueError(f"ImageEncoderViT.precision must be 'f16x3', 'f16' or 'f32', not {precision!r}")
+        plain, f32 = precision == "f16", precision == "f32"
         dev_ptr = _lib.params_key(self._sources())   # addresses + in-place versions of every parameter
-        hit = self._wcache.get(self.precision)
+        hit = self._wcache.get(precision)
         if hit is not None and hit[0] == dev_ptr:
             return hit[1]
         keep = []
@@ -174,15 +177,24 @@ class ImageEncoderViT(nn.Module):
         lin = [self.patch_embed.proj.weight, self.neck[0].weight, self.neck[2].weight] + [
             t for b in self.blocks for t in (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.lin1.weight, b.mlp.lin2.weight)]
         amax = float(torch.stack([t.detach().abs().max() for t in lin]).max())
-        if not amax * _lib.PLANES_W_SCALE < _lib.F16_MAX:
+        if not f32 and not amax * _lib.PLANES_W_SCALE < _lib.F16_MAX:
             self.overflow_events += 1
-            raise PopeRangeError(f"pope_amd: max |weight| = {amax:g} is outside the f16x3 range contract "
-                                 f"(|w| < {_lib.F16_MAX / _lib.PLANES_W_SCALE:g})")
+            msg = (f"pope_amd: max |weight| = {amax:g} is outside the f16x3 range contract "
+                   f"(|w| < {_lib.F16_MAX / _lib.PLANES_W_SCALE:g})")
+            if self.on_overflow == "raise":
+                raise PopeRangeError(msg)
+            import warnings
+            warnings.warn(msg + "; this encoder runs with precision='f32'")
+            w = self._weights("f32")
+            self._wcache[precision] = self._wcache["f32"]
+            return w
 
         def WP(t2d):
             k = t2d.shape[1]
             assert k % (64 if plain else 32) == 0
-            if plain:   # f16 row-major, value * 256
+            if f32:     # the fp32 matrix itself
+                pl = t2d.detach().float().contiguous()
+            elif plain:   # f16 row-major, value * 256
                 pl = (t2d.detach().float() * _lib.PLANES_W_SCALE).half().contiguous()
             else:
                 pl = _lib.to_planes(t2d.detach().float(), _lib.PLANES_W_SCALE)
@@ -214,7 +226,7 @@ class ImageEncoderViT(nn.Module):
         s = _lib.SamEncoderWeights()
         s.img, s.patch, s.dim, s.depth, s.heads = self.img_size, self.patch_size, dim, self.depth, self.num_heads
         s.hidden, s.out_chans, s.window = self.blocks[0].mlp.lin1.out_features, self.out_chans, self.window_size
-        s.precision = _lib.PREC_F16 if plain else _lib.PREC_F16X3
+        s.precision = _lib.PRECISIONS[precision]
         s.patch_wp, s.patch_b = WP(self.patch_embed.proj.weight.reshape(dim, -1)), P(self.patch_embed.proj.bias)
         s.pos = P(self.pos_embed.reshape(grid * grid, dim)) if self.pos_embed is not None else None
         s.ones = P(torch.ones(dim, device=dev))
@@ -225,7 +237,7 @@ class ImageEncoderViT(nn.Module):
         s.neck3_w, s.neck3_b = P(self.neck[3].weight), P(self.neck[3].bias)
         s.block_eps, s.neck_eps = self.block_eps, self.neck_eps
         keep.append(blocks)
-        self._wcache[self.precision] = (dev_ptr, s, keep)
+        self._wcache[precision] = (dev_ptr, s, keep)
         return s
 
     def _workspace(self, w, b, device):
@@ -236,7 +248,7 @@ class ImageEncoderViT(nn.Module):
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws
 
-    def _run(self, x, taps=()):
+    def _run(self, x, taps=(), precision=None):
         require_cuda(x, "ImageEncoderViT")
         if x.dtype != torch.float32:
             raise TypeError(f"ImageEncoderViT: expected float32, got {x.dtype}")
@@ -249,7 +261,7 @@ class ImageEncoderViT(nn.Module):
         tap_out = [torch.empty(b, grid, grid, self.embed_dim, device=x.device, dtype=torch.float32) for _ in taps]
         if b == 0:
             return out, tap_out
-        w = self._weights()
+        w = self._weights(precision)
         flag = torch.zeros(1, dtype=torch.int32, device=x.device)
         for s in range(0, b, self.max_batch):
             n = min(self.max_batch, b - s)
@@ -264,7 +276,12 @@ class ImageEncoderViT(nn.Module):
         if bits:
             self.overflow_events += 1
             what = ", ".join(v for k, v in _lib.RANGE_BITS.items() if bits & k)
-            raise PopeRangeError(f"pope_amd SAM encoder: a value left the f16x3 range ({what}); this encoder has no fp32 mode")
+            msg = f"pope_amd SAM encoder: a value left the f16x3 range ({what})"
+            if self.on_overflow == "raise":
+                raise PopeRangeError(msg)
+            import warnings
+            warnings.warn(msg + "; re-running the call on the fp32 MFMA")
+            return self._run(x, taps, precision="f32")
         return out, tap_out
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

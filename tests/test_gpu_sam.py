@@ -165,12 +165,39 @@ def test_contract_errors(hip_lib, golden_dir):
         m.blocks[0].mlp.lin1.weight[0, 0] += 0.5
         y1 = m(x.cuda())
     assert not torch.equal(y0, y1)
-    # ... and a weight set that leaves the f16x3 range is refused, not silently mangled
+    # ... and a weight set that leaves the f16x3 range is not silently mangled: it runs on the fp32 MFMA (or raises)
     from pope_amd.dinov2 import PopeRangeError
     with torch.no_grad():
         m.blocks[0].mlp.lin1.weight[0, 0] = 300.0
+    with pytest.warns(UserWarning, match="precision='f32'"):
+        y2 = m(x.cuda())
+    assert bool(torch.isfinite(y2).all())
+    m.on_overflow = "raise"
+    m._wcache = {}
     with pytest.raises(PopeRangeError):
         m(x.cuda())
+
+
+@pytest.mark.parametrize("name", ["sam_hd64_224", "sam_hd80_256", "sam_vit_b_1024", "sam_vit_h_1024"])
+def test_fp32_mfma_twin_matches_reference_fixture(hip_lib, golden_dir, name):
+    """precision = "f32" (sam_f32.hip: every contraction on the fp32 MFMA, a plain fp32 window / global attention with the
+    decomposed relative-position terms, fp32 LayerNorm2d and convolutions): the reference module's own arithmetic — held to
+    the same fixture bounds as f16x3 — and the path a range-guard event is re-run in."""
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    m, x, _ = build(fx)
+    m.precision = "f32"
+    with torch.no_grad():
+        check_against_fixture(m, x, fx, name + " [f32]")
+    # an activation outside the f16 range in the default mode: warning, fp32 re-run, the same answer as the f32 mode
+    m.precision = "f16x3"
+    xb = x.clone()
+    xb[0, 0, 5, 5] = 3.0e4
+    with torch.no_grad(), pytest.warns(UserWarning, match="fp32 MFMA"):
+        got = m(xb.cuda())
+    m.precision = "f32"
+    with torch.no_grad():
+        want = m(xb.cuda())
+    assert torch.equal(got, want) and bool(torch.isfinite(got).all()) and m.overflow_events == 1
 
 
 def test_default_norm_layer_eps_1e5(hip_lib):
