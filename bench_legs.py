@@ -308,8 +308,14 @@ def attention_ramp_leg(device, chunk=64, ntok=1531, heads=6, iters=10):
         for _ in range(3):
             call()
         ms, _ = _events_ms(call, iters)
+        ref_out = pout.clone()
+        n_exact = C.c_longlong(0)   # the diagnostic instantiation of the same kernel: identical results + a count of exact passes
+        _lib.check(lib.pope_attention_planes_diag_f32(C.c_void_p(pin.data_ptr()), C.c_void_p(pout.data_ptr()), chunk, ntok, heads,
+                                                      C.byref(n_exact), st), "pope_attention_planes_diag_f32")
+        wave_tiles = chunk * heads * (-(-ntok // 32)) * (-(-ntok // 64))
         out["ramps_log2_units_per_tile"][str(ramp)] = {"ms": round(ms, 4), "frac_of_f16_peak": round(fl / ms / 1e9 / PEAK_F16_MFMA_TFLOPS, 4),
-                                                       "finite": bool(torch.isfinite(pout.float()).all())}
+                                                       "exact_pass_rate": round(n_exact.value / wave_tiles, 4),
+                                                       "finite": bool(torch.isfinite(pout.float()).all()) and bool(torch.equal(pout, ref_out))}
         del pin
     out["note"] = ("ramp 0 = unstructured random scores (exact pass on the first tile only, like the bench's weights); 2.9 / 6.5 / 13 force "
                    "the exact pass on about every 2nd / every / every tile; results do not depend on the path taken "

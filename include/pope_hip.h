@@ -120,6 +120,13 @@ int pope_attention_prec_f32(const float* qkv, float* out, int B, int N, int head
  * pope_linear_planes_f32(..., c_planes), out_planes [B*N, heads*64] as read by the proj GEMM.  heads*64 % 32 == 0. */
 int pope_attention_planes_f32(const void* qkv_planes, void* out_planes, int B, int N, int heads, void* stream);
 
+/* Measurement only: pope_attention_planes_f32 through a diagnostic instantiation of the same kernel that counts the
+ * (wave, 64-key tile) pairs which took the lazy softmax's exact pass (*exact_passes_host; of B * heads * ceil(N / 32) *
+ * ceil(N / 64) pairs in all).  Same results; SYNCHRONISES the stream; a few % slower than the product kernel (the counter
+ * costs its hot loop registers), which is why the product kernel does not carry it.  bench.py's `attention_ramp` leg. */
+int pope_attention_planes_diag_f32(const void* qkv_planes, void* out_planes, int B, int N, int heads, long long* exact_passes_host,
+                                   void* stream);
+
 /* F.cosine_similarity(ref[1,D], fea[P,D], dim=1, eps) — eval_linemod_json.py:94. */
 int pope_cls_cosine_f32(const float* ref, const float* fea, int P, int D, float eps, float* scores,
                         void* stream);

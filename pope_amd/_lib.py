@@ -74,6 +74,7 @@ PROTOTYPES = {
     "pope_attention_prec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pope_patch_embed_planes_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pope_attention_planes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pope_attention_planes_diag_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, c_ll_p, C.c_void_p]),
     "pope_cls_cosine_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "pope_vit_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "pope_vit_forward_f32": (C.c_int, [C.POINTER(VitWeights), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -308,6 +308,10 @@ __device__ unsigned long long g_attn_dbg[32 * 8];
 #else
 #define ATTN_STAMP(t, slot) do {} while (0)
 #endif
+// Diagnostic instantiation only (template flag DIAG; bench.py's `attention_ramp` leg): (wave, 64-key tile) pairs that took the
+// exact pass since the last read.  NOT in the product kernel: a single relaxed atomic on the cold path costs the hot loop 16
+// spilled registers and 6 % (0.644 -> 0.685 ms, measured) — the loop sits at 256 VGPRs with zero slack.
+__device__ unsigned long long g_attn_exact_passes;
 constexpr int STAGE_H = 2 * (K_PLANE + V_PLANE);  // halves per K/V stage (Kh | Kl | Vh | Vl)
 constexpr size_t X3_ATTN_PIPE_BYTES = size_t(3) * STAGE_H * sizeof(_Float16);  // 129 024 B: three stages, see below
 static_assert(X3_ATTN_PIPE_BYTES >= X3_ATTN_EPI_BYTES, "epilogue staging fits the stages");
@@ -315,7 +319,7 @@ static_assert(X3_ATTN_PIPE_BYTES >= X3_ATTN_EPI_BYTES, "epilogue staging fits th
 // IN_PLANES: qkv is the planes tensor the QKV GEMM's epilogue writes (pope_hip.h layout, scale 8): K/V rows go to
 // LDS as they are (no per-tile hi/lo split: 48 VALU instructions, 8 LDS stores and a wait on loads issued one
 // iteration earlier per wave and tile -> 16-byte copies from registers loaded TWO iterations earlier).
-template <bool OUT_PLANES, bool IN_PLANES>
+template <bool OUT_PLANES, bool IN_PLANES, bool DIAG = false>
 __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                   int N, int heads) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -566,6 +570,8 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
             asm volatile("v_mov_b32 %0, %1" : "+v"(c0[i]) : "v"(d0[i]));
             asm volatile("v_mov_b32 %0, %1" : "+v"(c1[i]) : "v"(d1[i]));
         }
+        if constexpr (DIAG)
+            if (lane == 0) (void)__hip_atomic_fetch_add(&g_attn_exact_passes, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float delta = exact_prepare(c0, c1);
         sm_ls = f32x2{0.f, 0.f};
 #pragma unroll
@@ -822,6 +828,24 @@ extern "C" int pope_lab_attn_stamps(unsigned long long* host256) {
 
 int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream) {
     return launch_attn_x3<false>(qkv, out, B, N, heads, stream);
+}
+// the diagnostic twin of pope_launch_attention_f16x3_planes_io: same results, counts exact passes (slower: see above)
+int pope_launch_attention_f16x3_planes_io_diag(const void* qkv_planes, void* out_planes, int B, int N, int heads, long long* exact_passes_host,
+                                               hipStream_t stream) {
+    if (B <= 0 || N <= 0 || heads <= 0 || ((heads * HD) & 31) || size_t(B) * heads * ((N + QB - 1) / QB) > 0x7fffffffull) return POPE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(qkv_planes) & 15) || (reinterpret_cast<uintptr_t>(out_planes) & 15) || !exact_passes_host) return POPE_ERR_ARG;
+    if (size_t(N) * 3 * heads * HD * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
+    const dim3 grid(unsigned((N + QB - 1) / QB) * heads * B);
+    static pope_dev_mask lds_ok{0};
+    if (!pope_opt_in_lds(attn_f16x3_pipe_kernel<true, true, true>, X3_ATTN_PIPE_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
+    unsigned long long v = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_exact_passes), &v, sizeof(v)) != hipSuccess) return POPE_ERR_LAUNCH;
+    hipLaunchKernelGGL((attn_f16x3_pipe_kernel<true, true, true>), grid, dim3(NT), X3_ATTN_PIPE_BYTES, stream,
+                       static_cast<const float*>(qkv_planes), static_cast<float*>(out_planes), N, heads);
+    if (pope_check_launch() || hipStreamSynchronize(stream) != hipSuccess) return POPE_ERR_LAUNCH;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_attn_exact_passes), sizeof(v)) != hipSuccess) return POPE_ERR_LAUNCH;
+    *exact_passes_host = (long long)v;
+    return POPE_OK;
 }
 int pope_launch_attention_f16x3_planes_io(const void* qkv_planes, void* out_planes, int B, int N, int heads, hipStream_t stream) {
     if (B <= 0 || N <= 0 || heads <= 0 || ((heads * HD) & 31) || size_t(B) * heads * ((N + QB - 1) / QB) > 0x7fffffffull) return POPE_ERR_ARG;

@@ -193,6 +193,13 @@ int pope_attention_planes_f32(const void* qkv_planes, void* out_planes, int B, i
     return pope_launch_attention_f16x3_planes_io(qkv_planes, out_planes, B, N, heads, static_cast<hipStream_t>(stream));
 }
 
+int pope_attention_planes_diag_f32(const void* qkv_planes, void* out_planes, int B, int N, int heads, long long* exact_passes_host,
+                                   void* stream) {
+    StreamDevice on_device(stream);
+    if (!qkv_planes || !out_planes) return POPE_ERR_ARG;
+    return pope_launch_attention_f16x3_planes_io_diag(qkv_planes, out_planes, B, N, heads, exact_passes_host, static_cast<hipStream_t>(stream));
+}
+
 int pope_attention_f32(const float* qkv, float* out, int B, int N, int heads, void* stream) {
     return pope_attention_prec_f32(qkv, out, B, N, heads, POPE_PREC_F32_MFMA, nullptr, stream);
 }

@@ -139,6 +139,8 @@ int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int 
 // same, output as activation planes [B*N, heads*64] for the f16x3 proj GEMM
 int pope_launch_attention_f16x3_planes(const float* qkv, void* out_planes, int B, int N, int heads, hipStream_t stream);
 // qkv given as planes (the QKV GEMM epilogue's output), output planes: the whole-model f16x3 dataflow
+int pope_launch_attention_f16x3_planes_io_diag(const void* qkv_planes, void* out_planes, int B, int N, int heads, long long* exact_passes_host,
+                                               hipStream_t stream);   // diagnostic twin: counts exact passes, synchronises
 int pope_launch_attention_f16x3_planes_io(const void* qkv_planes, void* out_planes, int B, int N, int heads, hipStream_t stream);
 
 struct MatchParams {
