@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define POPE_ABI_VERSION 7
+#define POPE_ABI_VERSION 8
 
 enum {
     POPE_EPI_BIAS = 0,        /* C = A.W^T + bias                         nn.Linear                     */
@@ -395,8 +395,10 @@ int pope_crop_warp_u8(const unsigned char* img_hwc, int H, int W, int C, const d
  * winning hypothesis, winning root, matches of the pair, status (-1: counts exceed M)}.
  * The minimal samples of hypothesis h come from a counter-based hash of (seed, h): results do not depend on the batch a
  * pair rides in.  cv2's own random stream is not reproducible without cv2 (absent here): parity with OpenCV is unpinned,
- * the checker is oracle/pose_ref.py (same algorithm, same samples, numpy fp64). */
-size_t pope_estimate_pose_workspace_bytes(long long M);
+ * the checker is oracle/pose_ref.py (same algorithm, same samples, numpy fp64).
+ * Workspace (>= pope_estimate_pose_workspace_bytes(B, M), 32-byte aligned): normalised points and two masks per match, and per
+ * pair the list of one round's models (256 hypotheses x <= 10 roots x 9 fp64) that spreads the scoring evenly over the threads. */
+size_t pope_estimate_pose_workspace_bytes(int B, long long M);
 int pope_estimate_pose_f64(const float* kpts0, const float* kpts1, const int* counts, const double* K0, const double* K1,
                            int B, long long M, double thresh, double conf, int max_iters, unsigned long long seed,
                            double* R, double* t, double* E, unsigned char* inliers, int* info,

@@ -117,7 +117,7 @@ PROTOTYPES = {
     "pope_gray_u8_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pope_crop_warp_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p]),
-    "pope_estimate_pose_workspace_bytes": (C.c_size_t, [C.c_longlong]),
+    "pope_estimate_pose_workspace_bytes": (C.c_size_t, [C.c_int, C.c_longlong]),
     "pope_estimate_pose_f64": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_longlong, C.c_double, C.c_double, C.c_int, C.c_ulonglong]
                                + [C.c_void_p] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "pope_five_point_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -163,7 +163,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.pope_abi_version() != 7:
+        if handle.pope_abi_version() != 8:
             raise RuntimeError("libpope_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -719,7 +719,7 @@ int pope_streaming_top3_host(const float* scores, int P, float* slot_scores, lon
 
 }  // extern "C"
 
-size_t pope_estimate_pose_workspace_bytes(long long M) { return pope_pose_workspace(M); }
+size_t pope_estimate_pose_workspace_bytes(int B, long long M) { return pope_pose_workspace(B, M); }
 
 int pope_estimate_pose_f64(const float* kpts0, const float* kpts1, const int* counts, const double* K0, const double* K1, int B,
                            long long M, double thresh, double conf, int max_iters, unsigned long long seed, double* R, double* t,

@@ -300,7 +300,8 @@ struct PoseParams {
     unsigned char* inliers;                   // [M]
     int* info;                                // [B, 8]: n_good (0 = None), RANSAC inliers, hypotheses, rounds, best hypothesis, best root, N, status
     void* xn; unsigned char* mask_ws; unsigned char* cheir_ws;   // filled in by the launcher from the workspace
+    double* cand_ws; int* cmeta_ws;
 };
-size_t pope_pose_workspace(long long M);
+size_t pope_pose_workspace(int B, long long M);
 int pope_launch_estimate_pose(PoseParams q, void* ws, size_t ws_bytes, hipStream_t stream);
 int pope_launch_five_point(const double* x0, const double* x1, int S, double* E_out, int* n_out, hipStream_t stream);

@@ -26,14 +26,19 @@ constexpr int NT = pose::ROUND;
 #define POSE_STAMP(k) do {} while (0)
 #endif
 
+#define POSE_UNROLL _Pragma("unroll")
+
 struct __attribute__((aligned(32))) Pt { double ax, ay, bx, by; };
 
+// read of the per-pair model list written by other waves of the workgroup (device scope: not served from a stale L1 line)
+__device__ inline double list_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
-    __shared__ Pt s_pts[NT];
+    __shared__ Pt s_pts[NT + 4];           // + 4: the scoring loop prefetches past the tile's end (values unused)
     __shared__ double s_E[10][9];          // candidates handed to recoverPose (1 after RANSAC, <= 10 for the minimal problem)
     __shared__ double s_R1[9], s_R2[9], s_t[3];
     __shared__ unsigned long long s_key;
-    __shared__ int s_off, s_ncand, s_good[4];
+    __shared__ int s_off, s_ncand, s_good[4], s_total;
     const int b = blockIdx.x, tid = threadIdx.x;
 #ifdef POSE_STAMPS
     __shared__ unsigned long long stamps[8];
@@ -67,6 +72,8 @@ __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
     unsigned char* mask = q.mask_ws + off;
     unsigned char* cheir = q.cheir_ws + off;
     unsigned char* inl = q.inliers + off;
+    double* clist = q.cand_ws + size_t(b) * (NT * 10 * 9);   // this round's models, [<= NT * 10][9]
+    int* cmeta = q.cmeta_ws + size_t(b) * (NT * 10);          // their (hypothesis * 16 + root)
     const double* K0 = q.K0 + 9 * b;
     const double* K1 = q.K1 + 9 * b;
     // metrics.py:72-75: (kpts - [cx, cy]) / [fx, fy] in fp64; :78 threshold / mean(fx0, fy1, fx0, fy1)
@@ -85,25 +92,20 @@ __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
     const double t2 = thr * thr;
     __syncthreads();
 
-    if (N == 5) {
-        // the minimal problem itself: every solution goes to recoverPose, all five points count as inliers
-        if (tid == 0) {
-            double x0[10], x1[10];
-            for (int i = 0; i < 5; ++i) { x0[2 * i] = xn[i].ax; x0[2 * i + 1] = xn[i].ay; x1[2 * i] = xn[i].bx; x1[2 * i + 1] = xn[i].by; }
-            s_ncand = pose::five_point(x0, x1, s_E);
-            info[1] = 5; info[2] = 1; info[3] = 0; info[4] = 0; info[5] = 0;
-        }
-        __syncthreads();
-    } else {
+    const bool minimal = N == 5;             // the minimal problem itself: every solution goes to recoverPose, all five
+                                             // points count as inliers (one call site of the solver serves both cases)
+    {
         int niters = q.max_iters, done = 0, rounds = 0;
         unsigned long long best_key = 0ull;
         double cand[10][9];
         while (done < niters) {
+            if (tid == 0) s_total = 0;
+            __syncthreads();
             const int h = done + tid;
             int ncand = 0;
-            if (h < q.max_iters) {
-                int pick[5];
-                pose::sample_indices(q.seed, unsigned(h), unsigned(N), pick);
+            if (minimal ? tid == 0 : h < q.max_iters) {
+                int pick[5] = {0, 1, 2, 3, 4};
+                if (!minimal) pose::sample_indices(q.seed, unsigned(h), unsigned(N), pick);
                 double x0[10], x1[10];
                 for (int i = 0; i < 5; ++i) {
                     const Pt p = xn[pick[i]];
@@ -112,39 +114,86 @@ __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
                 ncand = pose::five_point(x0, x1, cand);
             }
             if (done == 0) POSE_STAMP(1);
+            if (minimal) {
+                if (tid == 0) {
+                    for (int k = 0; k < ncand; ++k)
+                        for (int j = 0; j < 9; ++j) s_E[k][j] = cand[k][j];
+                    s_ncand = ncand;
+                    info[1] = 5; info[2] = 1; info[3] = 0; info[4] = 0; info[5] = 0;
+                }
+                break;
+            }
+            // Score the round's models with the work spread evenly: a thread holds 0..10 roots (about 4 on average, and a
+            // wave would wait for its slowest lane), so the models go through a per-pair list in the workspace and thread i
+            // scores entries i, i + NT, ... of it -- ceil(total / NT) each, two at a time per point read.
+            int slot = 0;
+            if (ncand) slot = atomicAdd(&s_total, ncand);
+            for (int k = 0; k < ncand; ++k) {
+                for (int j = 0; j < 9; ++j) clist[size_t(slot + k) * 9 + j] = cand[k][j];
+                cmeta[slot + k] = h * 16 + k;
+            }
+            __threadfence();                 // the list is read by other waves: written back before the barrier, and read
+            __syncthreads();                 // below with agent-scope loads (the same addresses may sit stale in L1 from the
+            const int total = s_total;       // round before)
+            const int per = (total + NT - 1) / NT;
             int cnt[10];
+            POSE_UNROLL
             for (int k = 0; k < 10; ++k) cnt[k] = 0;
             for (int base = 0; base < N; base += NT) {
                 __syncthreads();
                 if (base + tid < N) s_pts[tid] = xn[base + tid];
                 __syncthreads();
                 const int m = min(NT, N - base);
-                for (int k = 0; k < ncand; ++k) {
-                    double E[9];
-                    for (int j = 0; j < 9; ++j) E[j] = cand[k][j];
-                    int c = 0;
-                    for (int i = 0; i < m; ++i) {
-                        const Pt p = s_pts[i];
-                        c += pose::sampson_inlier(E, p.ax, p.ay, p.bx, p.by, t2) ? 1 : 0;
+                POSE_UNROLL
+                for (int r = 0; r < 10; r += 2) {
+                    if (r < per) {           // uniform over the workgroup
+                        const int ca = tid + r * NT, cb = ca + NT;
+                        double Ea[9], Eb[9];
+                        POSE_UNROLL
+                        for (int j = 0; j < 9; ++j) {
+                            Ea[j] = ca < total ? list_load(clist + size_t(ca) * 9 + j) : 0.0;   // a zero model has no inliers
+                            Eb[j] = cb < total ? list_load(clist + size_t(cb) * 9 + j) : 0.0;
+                        }
+                        int na = 0, nb = 0;
+                        // one wave per SIMD: nothing else hides the LDS latency, so the next two points are fetched while
+                        // these two are scored (s_pts is padded by two entries for the reads past the end)
+                        Pt p0 = s_pts[0], p1 = s_pts[1];
+                        for (int i = 0; i < m; i += 2) {
+                            const Pt c0 = p0, c1 = p1;
+                            p0 = s_pts[i + 2]; p1 = s_pts[i + 3];
+                            na += pose::sampson_inlier(Ea, c0.ax, c0.ay, c0.bx, c0.by, t2) ? 1 : 0;
+                            nb += pose::sampson_inlier(Eb, c0.ax, c0.ay, c0.bx, c0.by, t2) ? 1 : 0;
+                            if (i + 1 < m) {
+                                na += pose::sampson_inlier(Ea, c1.ax, c1.ay, c1.bx, c1.by, t2) ? 1 : 0;
+                                nb += pose::sampson_inlier(Eb, c1.ax, c1.ay, c1.bx, c1.by, t2) ? 1 : 0;
+                            }
+                        }
+                        cnt[r] += na; cnt[r + 1] += nb;
                     }
-                    cnt[k] += c;
                 }
             }
             if (done == 0) POSE_STAMP(2);
             // the first model with the most inliers: (count, lowest hypothesis, lowest root) as one comparable key
-            int bk = -1, bc = 0;
-            for (int k = 0; k < ncand; ++k)
-                if (cnt[k] > bc) { bc = cnt[k]; bk = k; }
             unsigned long long key = 0ull;
-            if (bk >= 0 && bc >= 5) key = ((unsigned long long)bc << 32) | (0xFFFFFFFFull - (unsigned long long)(h * 16 + bk));
+            int kc = -1;
+            POSE_UNROLL
+            for (int r = 0; r < 10; ++r) {
+                const int c = tid + r * NT;
+                if (c < total && cnt[r] >= 5) {
+                    const unsigned meta = unsigned(__hip_atomic_load(cmeta + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const unsigned long long k2 = ((unsigned long long)cnt[r] << 32) | (0xFFFFFFFFull - (unsigned long long)meta);
+                    if (k2 > key) { key = k2; kc = c; }
+                }
+            }
             if (key) atomicMax(&s_key, key);
             __syncthreads();
             const unsigned long long win = s_key;
             if (win > best_key) {
                 best_key = win;
                 if (key == win) {
-                    for (int j = 0; j < 9; ++j) s_E[0][j] = cand[bk][j];
-                    info[4] = h; info[5] = bk;
+                    for (int j = 0; j < 9; ++j) s_E[0][j] = list_load(clist + size_t(kc) * 9 + j);
+                    const unsigned meta = 0xFFFFFFFFu - unsigned(win & 0xFFFFFFFFull);
+                    info[4] = int(meta >> 4); info[5] = int(meta & 15u);
                 }
             }
             done = min(done + NT, q.max_iters);
@@ -155,14 +204,16 @@ __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
             }
             __syncthreads();
         }
-        if (tid == 0) { info[2] = done; info[3] = rounds; info[1] = int(best_key >> 32); s_ncand = best_key ? 1 : 0; }
-        __syncthreads();
-        if (!best_key) return;               // "E is None" (metrics.py:82-84)
-        double E[9];
-        for (int j = 0; j < 9; ++j) E[j] = s_E[0][j];
-        for (int i = tid; i < N; i += NT) {
-            const Pt p = xn[i];
-            mask[i] = pose::sampson_inlier(E, p.ax, p.ay, p.bx, p.by, t2) ? 1 : 0;
+        if (!minimal) {
+            if (tid == 0) { info[2] = done; info[3] = rounds; info[1] = int(best_key >> 32); s_ncand = best_key ? 1 : 0; }
+            __syncthreads();
+            if (!best_key) return;           // "E is None" (metrics.py:82-84)
+            double E[9];
+            for (int j = 0; j < 9; ++j) E[j] = s_E[0][j];
+            for (int i = tid; i < N; i += NT) {
+                const Pt p = xn[i];
+                mask[i] = pose::sampson_inlier(E, p.ax, p.ay, p.bx, p.by, t2) ? 1 : 0;
+            }
         }
         __syncthreads();
     }
@@ -239,20 +290,22 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
 }  // namespace
 
-size_t pope_pose_workspace(long long M) {
-    const size_t m = size_t(M < 1 ? 1 : M);
-    return align256(m * sizeof(Pt)) + 2 * align256(m);
+size_t pope_pose_workspace(int B, long long M) {
+    const size_t m = size_t(M < 1 ? 1 : M), nb = size_t(B < 1 ? 1 : B);
+    return align256(m * sizeof(Pt)) + 2 * align256(m) + align256(nb * NT * 10 * 9 * sizeof(double)) + align256(nb * NT * 10 * sizeof(int));
 }
 
 int pope_launch_estimate_pose(PoseParams q, void* ws, size_t ws_bytes, hipStream_t stream) {
     if (!q.kpts0 || !q.kpts1 || !q.counts || !q.K0 || !q.K1 || !q.R || !q.t || !q.E || !q.inliers || !q.info || !ws) return POPE_ERR_ARG;
     if (q.B <= 0 || q.M < 0 || q.max_iters < 1 || !(q.thresh > 0.0) || (reinterpret_cast<uintptr_t>(ws) & 31)) return POPE_ERR_ARG;
-    if (ws_bytes < pope_pose_workspace(q.M)) return POPE_ERR_WORKSPACE;
+    if (ws_bytes < pope_pose_workspace(q.B, q.M)) return POPE_ERR_WORKSPACE;
     const size_t m = size_t(q.M < 1 ? 1 : q.M);
     char* p = static_cast<char*>(ws);
     q.xn = p; p += align256(m * sizeof(Pt));
     q.mask_ws = reinterpret_cast<unsigned char*>(p); p += align256(m);
-    q.cheir_ws = reinterpret_cast<unsigned char*>(p);
+    q.cheir_ws = reinterpret_cast<unsigned char*>(p); p += align256(m);
+    q.cand_ws = reinterpret_cast<double*>(p); p += align256(size_t(q.B) * NT * 10 * 9 * sizeof(double));
+    q.cmeta_ws = reinterpret_cast<int*>(p);
     hipLaunchKernelGGL(pose_kernel, dim3(q.B), dim3(NT), 0, stream, q);
     return pope_check_launch();
 }

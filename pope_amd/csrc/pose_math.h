@@ -10,9 +10,11 @@
 #define POPE_HD __host__ __device__ inline __attribute__((always_inline))   // helpers taking array pointers must inline, or the
                                                                             // arrays they touch are pinned to scratch memory
 #define POPE_UNROLL _Pragma("unroll")   // small fixed loops over thread-private arrays: keeps them in registers (no scratch)
+#define POPE_ROLLED _Pragma("nounroll")  // a loop around a large inlined body that must stay one copy (instruction cache)
 #else
 #define POPE_HD inline __attribute__((always_inline))
 #define POPE_UNROLL
+#define POPE_ROLLED
 #endif
 
 namespace pose {
@@ -61,69 +63,139 @@ POPE_HD void mac_ql(double* c, const double* q, const double* l, double s) {
 }
 
 // ---- real roots of a polynomial of degree <= 10 by Sturm sequences -----------------------------------------------------
+// Every array below is indexed by unrolled loop counters only (bounds that depend on data are predicates, not trip counts):
+// the chain then lives in registers on the device instead of scratch memory.  Polynomials are stored LEADING COEFFICIENT
+// FIRST: g[m] = coefficient of t^(deg - m), zeros after position deg, so that a division step and Horner's rule touch
+// positions that are sums of loop counters.
 struct Sturm {
-    double f[12][11];   // chain polynomials, f[i][k] = coefficient of t^k
-    int deg[12];
+    double g[11][11];   // chain polynomial i has degree <= 10 - i
+    int deg[11];
     int len;
 };
-POPE_HD int poly_degree(const double* c, int d, double tol) {
-    while (d > 0 && fabs(c[d]) <= tol) --d;
-    return d;
+// drop leading coefficients that vanished (|g[0]| <= tol) from a polynomial of degree <= MAXD
+template <int MAXD>
+POPE_HD void strip_leading(double* g, int& deg, double tol) {
+    POPE_UNROLL
+    for (int s = 0; s < MAXD; ++s) {
+        const bool sh = deg > 0 && fabs(g[0]) <= tol;
+        POPE_UNROLL
+        for (int m = 0; m < MAXD; ++m) g[m] = sh ? g[m + 1] : g[m];
+        g[MAXD] = sh ? 0.0 : g[MAXD];
+        deg -= sh ? 1 : 0;
+    }
 }
+template <int MAXD>
+POPE_HD double horner_lead(const double* g, int deg, double t) {
+    double v = g[0];
+    POPE_UNROLL
+    for (int m = 1; m <= MAXD; ++m) v = (m <= deg) ? v * t + g[m] : v;
+    return v;
+}
+// link I of the chain: g[I] = -(g[I-2] mod g[I-1]), rescaled; returns false when the chain ends before it
+template <int I>
+POPE_HD bool sturm_link(Sturm& s) {
+    constexpr int MA = 12 - I, MB = 11 - I;      // largest degrees g[I-2] and g[I-1] can have
+    const int da = s.deg[I - 2], db = s.deg[I - 1];
+    if (!(db > 0)) return false;
+    const double* a = s.g[I - 2];
+    const double* b = s.g[I - 1];
+    const int dq = da - db;                       // >= 1
+    double r[MA + 1];
+    POPE_UNROLL
+    for (int m = 0; m <= MA; ++m) r[m] = a[m];
+    POPE_UNROLL
+    for (int t = 0; t < MA; ++t) {                // long division r <- a mod b: dq + 1 steps (two, unless degrees dropped)
+        if (t <= dq) {
+            const double q = r[t] / b[0];
+            POPE_UNROLL
+            for (int j = 1; j <= MB; ++j)
+                if (t + j <= MA) r[t + j] -= q * b[j];      // b is zero after position db: those steps change nothing
+            r[t] = 0.0;
+        }
+    }
+    double rm = 0.0, bm = 0.0;                    // the remainder sits at positions dq + 1 .. da, zeros everywhere else
+    POPE_UNROLL
+    for (int m = 0; m <= MA; ++m) { rm = fmax(rm, fabs(r[m])); bm = fmax(bm, fabs(a[m])); }
+    if (!(rm > 1e-13 * bm)) return false;         // exact division: a and b share the remaining factor (multiple roots)
+    const int sh = dq + 1;                        // move it to the front: shifts by 1, 2, 4, 8 as sh has the bits
+    POPE_UNROLL
+    for (int bit = 1; bit <= 8; bit *= 2) {
+        const bool on = (sh & bit) != 0;
+        POPE_UNROLL
+        for (int m = 0; m <= MA; ++m) r[m] = on ? (m + bit <= MA ? r[m + bit] : 0.0) : r[m];
+    }
+    const double inv = -1.0 / rm;                 // negated remainder; the positive rescaling keeps the signs
+    double* o = s.g[I];
+    POPE_UNROLL
+    for (int m = 0; m <= 10; ++m) o[m] = (m < MB) ? r[m] * inv : 0.0;
+    int d = db - 1;
+    strip_leading<MB - 1>(o, d, 1e-13);
+    s.deg[I] = d;
+    s.len = I + 1;
+    return true;
+}
+// c[k] = coefficient of t^k, k <= d <= 10
 POPE_HD void sturm_build(Sturm& s, const double* c, int d) {
     double mx = 0.0;
     for (int k = 0; k <= d; ++k) mx = fmax(mx, fabs(c[k]));
-    for (int k = 0; k <= 10; ++k) s.f[0][k] = (k <= d && mx > 0.0) ? c[k] / mx : 0.0;
-    s.deg[0] = poly_degree(s.f[0], d, 1e-14);
-    for (int k = 0; k <= 10; ++k) s.f[1][k] = (k + 1 <= s.deg[0]) ? (k + 1) * s.f[0][k + 1] : 0.0;
-    s.deg[1] = s.deg[0] > 0 ? s.deg[0] - 1 : 0;
-    s.len = 2;
-    if (s.deg[0] == 0) { s.len = 1; return; }
-    while (s.deg[s.len - 1] > 0 && s.len < 12) {
-        const double* a = s.f[s.len - 2];
-        const double* b = s.f[s.len - 1];
-        const int da = s.deg[s.len - 2], db = s.deg[s.len - 1];
-        double r[11];
-        for (int k = 0; k <= 10; ++k) r[k] = a[k];
-        for (int k = da; k >= db; --k) {          // long division: r <- a mod b
-            const double q = r[k] / b[db];
-            for (int j = 0; j <= db; ++j) r[k - db + j] -= q * b[j];
-            r[k] = 0.0;
-        }
-        double rm = 0.0;
-        for (int k = 0; k < db; ++k) rm = fmax(rm, fabs(r[k]));
-        double bm = 0.0;
-        for (int k = 0; k <= da; ++k) bm = fmax(bm, fabs(a[k]));
-        if (!(rm > 1e-13 * bm)) break;            // exact division: a and b share the remaining factor (multiple roots)
-        double* o = s.f[s.len];
-        for (int k = 0; k <= 10; ++k) o[k] = (k < db) ? -r[k] / rm : 0.0;   // positive rescaling keeps the signs
-        s.deg[s.len] = poly_degree(o, db - 1, 1e-13);
-        ++s.len;
+    POPE_UNROLL
+    for (int i = 0; i <= 10; ++i) {
+        s.deg[i] = 0;
+        POPE_UNROLL
+        for (int m = 0; m <= 10; ++m) s.g[i][m] = 0.0;
     }
+    POPE_UNROLL
+    for (int m = 0; m <= 10; ++m) s.g[0][m] = (m <= d && mx > 0.0) ? c[d - m] / mx : 0.0;
+    int d0 = d;
+    strip_leading<10>(s.g[0], d0, 1e-14);
+    s.deg[0] = d0;
+    s.len = 1;
+    if (d0 == 0) return;
+    POPE_UNROLL
+    for (int m = 0; m <= 9; ++m) s.g[1][m] = (m < d0) ? double(d0 - m) * s.g[0][m] : 0.0;
+    s.deg[1] = d0 - 1;
+    s.len = 2;
+    // each link ends the chain for good when it fails
+    if (!sturm_link<2>(s)) return;
+    if (!sturm_link<3>(s)) return;
+    if (!sturm_link<4>(s)) return;
+    if (!sturm_link<5>(s)) return;
+    if (!sturm_link<6>(s)) return;
+    if (!sturm_link<7>(s)) return;
+    if (!sturm_link<8>(s)) return;
+    if (!sturm_link<9>(s)) return;
+    sturm_link<10>(s);
 }
-POPE_HD double horner(const double* c, int d, double t) {
-    double v = c[d];
-    for (int k = d - 1; k >= 0; --k) v = v * t + c[k];
-    return v;
-}
-POPE_HD int sturm_changes(const Sturm& s, double t) {
-    int n = 0, last = 0;
-    for (int i = 0; i < s.len; ++i) {
-        const double v = horner(s.f[i], s.deg[i], t);
+template <int I>
+POPE_HD void sturm_sign(const Sturm& s, double t, int& n, int& last) {
+    if (I < s.len) {
+        const double v = horner_lead<10 - I>(s.g[I], s.deg[I], t);
         const int sg = v > 0.0 ? 1 : (v < 0.0 ? -1 : 0);
         if (sg != 0) {
             if (last != 0 && sg != last) ++n;
             last = sg;
         }
     }
+}
+POPE_HD int sturm_changes(const Sturm& s, double t) {
+    int n = 0, last = 0;
+    sturm_sign<0>(s, t, n, last); sturm_sign<1>(s, t, n, last); sturm_sign<2>(s, t, n, last); sturm_sign<3>(s, t, n, last);
+    sturm_sign<4>(s, t, n, last); sturm_sign<5>(s, t, n, last); sturm_sign<6>(s, t, n, last); sturm_sign<7>(s, t, n, last);
+    sturm_sign<8>(s, t, n, last); sturm_sign<9>(s, t, n, last); sturm_sign<10>(s, t, n, last);
     return n;
+}
+// value of a polynomial given lowest coefficient first (the small fixed-degree ones of the solver)
+POPE_HD double horner(const double* c, int d, double t) {
+    double v = c[d];
+    for (int k = d - 1; k >= 0; --k) v = v * t + c[k];
+    return v;
 }
 // distinct real roots of c (degree d) in (lo, hi], ascending -> out[]; returns their number (<= 10)
 POPE_HD int sturm_roots(const double* c, int d, double lo, double hi, double* out) {
     Sturm s;
     sturm_build(s, c, d);
     if (s.deg[0] == 0) return 0;
-    const double* p = s.f[0];
+    const double* p = s.g[0];
     const int dp = s.deg[0];
     double slo[12], shi[12];
     int vlo[12], vhi[12];
@@ -144,18 +216,20 @@ POPE_HD int sturm_roots(const double* c, int d, double lo, double hi, double* ou
             } else if (va - vm > 0) { b = m; vb = vm; }
             else { a = m; va = vm; }
         }
-        double fa = horner(p, dp, a), fb = horner(p, dp, b);
+        double fa = horner_lead<10>(p, dp, a), fb = horner_lead<10>(p, dp, b);
         double root;
         if (fb == 0.0) root = b;
         else if ((fa < 0.0) != (fb < 0.0) && fa != 0.0) {
             for (int it = 0; it < 10; ++it) {     // bisection, then Newton inside the bracket
-                const double m = 0.5 * (a + b), fm = horner(p, dp, m);
+                const double m = 0.5 * (a + b), fm = horner_lead<10>(p, dp, m);
                 if ((fm < 0.0) == (fa < 0.0)) { a = m; fa = fm; } else { b = m; fb = fm; }
             }
             root = 0.5 * (a + b);
             for (int it = 0; it < 12; ++it) {
-                double v = p[dp], dv = 0.0;
-                for (int k = dp - 1; k >= 0; --k) { dv = dv * root + v; v = v * root + p[k]; }
+                double v = p[0], dv = 0.0;
+                POPE_UNROLL
+                for (int m = 1; m <= 10; ++m)
+                    if (m <= dp) { dv = dv * root + v; v = v * root + p[m]; }
                 if ((v < 0.0) == (fa < 0.0)) { a = root; } else { b = root; }
                 double nx = dv != 0.0 ? root - v / dv : 0.5 * (a + b);
                 if (!(nx > a && nx < b)) nx = 0.5 * (a + b);
@@ -315,10 +389,17 @@ POPE_HD int five_point(const double* x0, const double* x1, double (*E_out)[9]) {
     double zs[20];
     int nz = 0;
     {
-        double ru[10], rz[10], rev[11];
-        for (int k = 0; k <= 10; ++k) rev[k] = poly[10 - k];
-        const int nu = sturm_roots(rev, 10, -1.0, 1.0, ru);
-        const int n1 = sturm_roots(poly, 10, -1.0, 1.0, rz);
+        double rr[2][10];
+        int nr[2];
+        POPE_ROLLED
+        for (int pass = 0; pass < 2; ++pass) {      // one copy of the root finder in the code: u first, then z
+            double cur[11];
+            for (int k = 0; k <= 10; ++k) cur[k] = pass ? poly[k] : poly[10 - k];
+            nr[pass] = sturm_roots(cur, 10, -1.0, 1.0, rr[pass]);
+        }
+        const double* ru = rr[0];
+        const double* rz = rr[1];
+        const int nu = nr[0], n1 = nr[1];
         // ascending z: z < -1 are the u in (-1, 0) taken from the one closest to 0 backwards, then (-1, 1], then z > 1 = the u
         // in (0, 1) again from the largest downwards (u = 1 is z = 1, already counted; u = 0 is a root at infinity)
         for (int i = nu - 1; i >= 0; --i)

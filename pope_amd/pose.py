@@ -63,7 +63,7 @@ def estimate_pose_batch(kpts0, kpts1, counts, K0, K1, thresh, conf=0.99999, seed
     if B == 0:
         return {"R": R, "t": t, "E": E, "inliers": inl[:M].bool(), "n_inliers": info[:, 0], "info": info}
     lib = _lib.lib()
-    nbytes = lib.pope_estimate_pose_workspace_bytes(M)
+    nbytes = lib.pope_estimate_pose_workspace_bytes(B, M)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
     with on_device_of(kpts0):

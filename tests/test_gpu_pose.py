@@ -71,8 +71,11 @@ def test_batch_against_oracle_same_samples(dev):
         assert (info[b, 4], info[b, 5]) == oi["best"] and info[b, 1] == oi["inliers"]
         assert info[b, 2] == oi["hypotheses"] and info[b, 3] == oi["rounds"]
         assert np.array_equal(inl[off:off + n], ret[2]) and info[b, 0] == int(ret[2].sum())
-        np.testing.assert_allclose(R[b], ret[0], atol=1e-7)
-        np.testing.assert_allclose(t[b], ret[1], atol=1e-7)
+        # the winner is the same ROOT of the same tenth-degree polynomial on both sides, found by different methods (Sturm
+        # isolation + Newton here, companion-matrix eigenvalues in the checker): the pose inherits eps x the root's
+        # condition number (up to ~1e9 for these samples), hence 1e-6 and not 1e-12
+        np.testing.assert_allclose(R[b], ret[0], atol=1e-6)
+        np.testing.assert_allclose(t[b], ret[1], atol=1e-6)
         off += n
 
 
