@@ -383,7 +383,7 @@ int pope_crop_warp_u8(const unsigned char* img_hwc, int H, int W, int C, const d
  * both point sets (:72-75), threshold = thresh / mean(fx0, fy1, fx0, fy1) (:78), essential matrix by RANSAC over five-point
  * minimal samples (what cv2.findEssentialMat(..., cv2.RANSAC) does: Sampson error <= threshold^2, a model is kept when it has
  * MORE inliers than the best so far and at least five, budget log(1 - conf) / log(1 - w^5) re-evaluated after every round of
- * 256 hypotheses, at most max_iters — OpenCV's default is 1000), then recoverPose for every returned E (:86-94): the
+ * 256 hypotheses, at most max_iters <= 2^27 — OpenCV's default is 1000), then recoverPose for every returned E (:86-94): the
  * (R, t) of the four decompositions with the most inliers in front of both cameras.  A pair with exactly five matches is
  * the minimal problem itself: all of its solutions go through recoverPose.  All arithmetic fp64.
  * Inputs are the dense matcher's compacted outputs as they lie in HBM: kpts0 / kpts1 [M, 2] fp32 pixel coordinates with

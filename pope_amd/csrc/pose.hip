@@ -297,7 +297,8 @@ size_t pope_pose_workspace(int B, long long M) {
 
 int pope_launch_estimate_pose(PoseParams q, void* ws, size_t ws_bytes, hipStream_t stream) {
     if (!q.kpts0 || !q.kpts1 || !q.counts || !q.K0 || !q.K1 || !q.R || !q.t || !q.E || !q.inliers || !q.info || !ws) return POPE_ERR_ARG;
-    if (q.B <= 0 || q.M < 0 || q.max_iters < 1 || !(q.thresh > 0.0) || (reinterpret_cast<uintptr_t>(ws) & 31)) return POPE_ERR_ARG;
+    if (q.B <= 0 || q.M < 0 || q.max_iters < 1 || q.max_iters > (1 << 27) || !(q.thresh > 0.0) || (reinterpret_cast<uintptr_t>(ws) & 31))
+        return POPE_ERR_ARG;                 // the winner's key carries hypothesis * 16 + root in 32 bits
     if (ws_bytes < pope_pose_workspace(q.B, q.M)) return POPE_ERR_WORKSPACE;
     const size_t m = size_t(q.M < 1 ? 1 : q.M);
     char* p = static_cast<char*>(ws);
