@@ -84,6 +84,36 @@ def test_scaling_reproduces_a_linear_ramp():
     assert np.all(out[sy < -1.01] == 0) and np.all(out[sy > h + 0.01] == 0)       # rows beyond the crop: zero padding
 
 
+def test_warp_agrees_with_an_independent_float_bilinear():
+    """cv2 is absent, so the fixed-point restatement is also held to an independent implementation: scipy's float bilinear
+    sampling (order 1, constant 0 outside) at the exactly inverse-mapped coordinates.  On a smooth image (gradient G levels
+    per pixel) the two may differ by the 1/32-pixel position truncation (G / 32 per axis), the 10-bit weights and the final
+    rounding; the mean signed difference shows the truncation's half-step bias only."""
+    from scipy import ndimage
+    yy, xx = np.mgrid[0:150, 0:200].astype(np.float64)
+    base = 128 + 60 * np.sin(xx / 25) * np.cos(yy / 40) + 50 * np.cos(yy / 20 + xx / 90)
+    img = np.round(base).astype(np.uint8)
+    gy, gx = np.gradient(img.astype(np.float64))
+    G = max(np.abs(gx).max(), np.abs(gy).max())
+    assert G <= 6.0
+    for center, scale, rot, size in [((100.0, 75.0), 90.0, 0.0, (256, 256)), ((60.5, 80.25), 140.0, 0.0, (256, 256)),
+                                     ((120.0, 70.0), 77.0, 30.0, (192, 160))]:
+        M = R.get_affine_transform(np.array(center, np.float32), scale, rot, size)
+        out = R.warp_affine_u8(img, M, size)
+        Mi = R.invert_affine(M)
+        Y, X = np.mgrid[0:size[1], 0:size[0]].astype(np.float64)
+        sx = Mi[0, 0] * X + Mi[0, 1] * Y + Mi[0, 2]
+        sy = Mi[1, 0] * X + Mi[1, 1] * Y + Mi[1, 2]
+        want = ndimage.map_coordinates(img.astype(np.float64), [sy, sx], order=1, mode="constant", cval=0.0)
+        inside = (sx >= 1) & (sx <= img.shape[1] - 2) & (sy >= 1) & (sy <= img.shape[0] - 2)
+        d = out.astype(np.float64) - want
+        assert inside.sum() > 5000
+        assert np.abs(d[inside]).max() <= 0.5 + 2 * G / 32 + 0.05, (center, scale, rot, np.abs(d[inside]).max())
+        assert abs(d[inside].mean()) <= G / 32
+        far = (sx < -1.01) | (sx > img.shape[1] + 0.01) | (sy < -1.01) | (sy > img.shape[0] + 0.01)
+        assert np.all(out[far] == 0)
+
+
 def test_two_step_crop_equals_one_composite_gather():
     """The reference's crop-then-resize (two warps, an intermediate zero-padded crop) == sampling the frame through the
     crop window directly — the identity the one-launch GPU kernel relies on."""
