@@ -12,11 +12,14 @@ reported next to a bounded CPU run of the oracle:
 
 The oracle (oracle/) is imported here for the `cpu_baseline` entries only, after the timed regions.
 """
+import json
 import os
 import time
 
 import numpy as np
 import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
 
 PEAK_F16_MFMA_TFLOPS = 2500.0
 
@@ -103,16 +106,22 @@ def loftr_matcher_leg(matcher, device, n_pairs, iters=10, cpu_baseline=False):
             bad.append(f"pair {k}: conf_matrix differs from the batch-1 call")
     fl = 2 * n_pairs * loftr_cnn_flops(256, 256)
     tf = fl / cnn_ms / 1e9
+    traffic = None   # HBM bytes of one call from the committed rocprofv3 --pmc passes (scripts/pmc_cnn.sh), not measured in this run
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_cnn.json"))).get(f"resnet_fpn_{2 * n_pairs}_images", {}).get("bytes")
+    except (OSError, ValueError):
+        pass
     out = {"value": round(n_pairs * 1e3 / ms, 1), "unit": "LoFTR pairs/s", "pairs": n_pairs, "image": [256, 256], "ms_per_call": round(ms, 3),
            "matches": int(len(d["b_ids"])), "verified": not bad,
            "stages_ms": {"resnet_fpn": round(cnn_ms, 3), "coarse_transformer_8_layers": round(xf_ms, 3),
                          "coarse_match_fine_stage_and_host": round(ms - cnn_ms - xf_ms, 3)},
            "roofline": {"kernel": "ResNetFPN_8_2 forward (22 convolutions on gemm_planes16_kernel<EPI_CONV>; one C call)", "bound": "mfma",
                         "achieved": round(tf, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4),
-                        "frac_of_executed_mfma_flops": round(3 * tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
+                        "frac_of_executed_mfma_flops": round(3 * tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
                         "flops_per_launch": fl, "avg_ms_per_launch": round(cnn_ms, 4), "launches_timed": iters,
                         "note": f"{2 * n_pairs} images of 256x256 per call, {loftr_cnn_flops(256, 256) / 1e9:.2f} GFLOP each (closed form of "
-                                "resnet_fpn.py:43-118); HIP events around the C call on the launch stream; f16x3 arithmetic"}}
+                                "resnet_fpn.py:43-118); HIP events around the C call on the launch stream; f16x3 arithmetic; `traffic` = HBM bytes "
+                                "per call from the committed PMC passes (profiles/r03/pmc_cnn.json)"}}
     if bad:
         out["verify_failures"] = bad[:6]
     if cpu_baseline:

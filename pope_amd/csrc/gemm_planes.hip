@@ -84,7 +84,12 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
     // CONV: byte offset of the next K-step's A rows = (dy * Wp + dx) rows + chunk * 128, kept incrementally (scalar
     // selects: the K-step stays one basic block)
     const int cv_row = g.lda * 4, cv_dy = (g.conv_wp - 2) * cv_row;
-    int cv_chunk = 0, cv_dx = 0, cv_off = 0;
+    // K order CHUNK-major: the nine taps of a 32-channel chunk back to back, so that the three tap rows — three different
+    // image rows, each also read by the tiles above and below — are touched within nine K-steps of each other instead of
+    // 3 * chunks apart.  Tap-major order let the 4 MB L2 of an XCD turn over in between: PMC fetch 3.2x (128 channels) to
+    // 8.5x (224) the input, 38.6 GB per 48-image ResNet-FPN call against 22.6 GB now (profiles/r03/pmc_cnn.json).  W's K
+    // offset (tap * chunks + chunk: the folded matrices keep their tap-major columns) is its own counter.
+    int cv_chunk = 0, cv_dx = 0, cv_off = 0, cv_dyi = 0, cv_w = 0;
 
     // Tile stream of this persistent workgroup (gemm_f16x3.hip has the measurements behind every choice here): full
     // rounds by XCD-remapped id, the partial last round one tile per CU by raw blockIdx; the K-steps of consecutive
@@ -123,16 +128,20 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned vw = unsigned(n0 + prow + 32 * i) * unsigned(g.ldw) * 4u + pc * 16u;
-            st[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, ld_kt * 128, 0);
+            st[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, CONV ? cv_w : ld_kt * 128, 0);
         }
         const int wrap = ++ld_kt == nk;
         if constexpr (CONV) {
-            const int cwrap = ++cv_chunk == g.conv_cch;                  // next tap
-            cv_chunk = pope_uniform_select(cwrap, 0, cv_chunk);
-            const int xwrap = cwrap & (cv_dx == 2);                       // next tap row
-            cv_off += pope_uniform_select(cwrap, pope_uniform_select(xwrap, cv_dy, cv_row), 0);
-            cv_dx = pope_uniform_select(cwrap, pope_uniform_select(xwrap, 0, cv_dx + 1), cv_dx);
-            cv_off = pope_uniform_select(wrap, 0, cv_off);                // next tile: tap (0, 0) again
+            const int xw = cv_dx == 2;                                    // end of a tap row
+            const int tw = xw & (cv_dyi == 2);                            // ninth tap done: next channel chunk
+            cv_off += pope_uniform_select(xw, cv_dy, cv_row);
+            cv_off = pope_uniform_select(tw, 0, cv_off);
+            cv_dx = pope_uniform_select(xw, 0, cv_dx + 1);
+            cv_dyi = pope_uniform_select(tw, 0, cv_dyi + xw);
+            cv_chunk += tw;
+            cv_w = pope_uniform_select(tw, cv_chunk * 128, cv_w + g.conv_cch * 128);   // W column block = tap * cch + chunk
+            cv_chunk = pope_uniform_select(wrap, 0, cv_chunk);            // next tile
+            cv_w = pope_uniform_select(wrap, 0, cv_w);
         }
         ld_kt = pope_uniform_select(wrap, 0, ld_kt);
         ld_ord += wrap;
