@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // Same LayerNorm, output as f16 hi/lo planes for the f16x3 GEMMs (y*scale = hi + lo): the split is
 // done once here, in an HBM-bound kernel with idle VALU, instead of per K-step in every GEMM tile.
@@ -226,6 +227,71 @@ __global__ __launch_bounds__(256) void im2col_planes_kernel(const float* __restr
     pope_range_flag(flag, POPE_RANGE_PATCH, nonfinite || !(amax < POPE_F16_OVERFLOW));
 }
 
+// The same operand by strips: one workgroup per (image, patch row, group of IM2_P patches).  The 3 * patch image-row
+// segments of the group are read once, coalesced, and scattered into LDS in OUTPUT order (per patch: k = c p^2 + dy p + dx);
+// every thread then turns 8 consecutive k of one patch (two 16-byte LDS reads) into a 16-byte hi piece and its lo twin.  The
+// per-(row, k) kernel above pays two divisions by run-time values per element (VALU-bound) and leaves neighbouring patches
+// — which share every 128-byte line of the image — to workgroups on different XCDs (PMC fetch 3.2x the image).
+constexpr int IM2_P = 16;
+__global__ __launch_bounds__(256) void im2col_planes_strip_kernel(const float* __restrict__ img, _Float16* __restrict__ pl,
+                                                                   int B, int H, int W, int patch, int kp, int ntok, int gw,
+                                                                   int groups, unsigned* flag) {
+    extern __shared__ __attribute__((aligned(16))) float seg[];   // [IM2_P][kp + 4]: the +4 floats skew the patches' banks
+    const int gh = H / patch, ks = kp + 4;
+    const int grp = blockIdx.x % groups, py = (blockIdx.x / groups) % gh, b = blockIdx.x / (groups * gh);
+    const int px0 = grp * IM2_P, np = min(IM2_P, gw - px0);
+    const int half_len = (np * patch) >> 1, nseg = 3 * patch, pp = patch * patch, k_real = 3 * pp;
+    for (int i = threadIdx.x; i < np * (kp - k_real); i += 256) {        // padding columns read as zeros
+        const int p = i / (kp - k_real);
+        seg[p * ks + k_real + (i - p * (kp - k_real))] = 0.f;
+    }
+    // a segment is at most IM2_P * patch / 2 float2's: `lanes` threads per segment, 256 / lanes segments per pass
+    const int lanes = half_len <= 32 ? 32 : half_len <= 64 ? 64 : half_len <= 128 ? 128 : 256;
+    const int sub = threadIdx.x / lanes, j0 = threadIdx.x - sub * lanes, per_pass = 256 / lanes;
+    for (int j = j0; j < half_len; j += lanes) {                          // one trip when half_len <= lanes
+        const int p = (2 * j) / patch, dx = 2 * j - p * patch;            // patch is even: the pair stays inside one patch
+        // segment sgi = c * patch + dy is image row (c H + py patch + dy): the row index advances by per_pass, plus
+        // H - patch whenever dy wraps into the next channel (no division in the loop; eight loads in flight)
+        const float* src = img + ((size_t(b) * 3 * H + size_t(py) * patch) * W + px0 * patch + 2 * j);
+        float* dst = seg + p * ks + dx;
+        int dy = sub % patch, c = sub / patch;
+#pragma unroll 8
+        for (int sgi = sub; sgi < nseg; sgi += per_pass) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(src + (size_t(c) * H + dy) * W);
+            *reinterpret_cast<f32x2*>(dst + sgi * patch) = v;                 // c pp + dy patch == sgi patch
+            dy += per_pass;
+            if (dy >= patch) { dy -= patch; ++c; }
+        }
+    }
+    __syncthreads();
+    float amax = 0.f;
+    bool nonfinite = false;
+    const int pieces = kp >> 3;                                            // 8 k values per piece
+    const size_t row0 = size_t(b) * ntok + 1 + size_t(py) * gw + px0;
+    for (int i = threadIdx.x; i < np * pieces; i += 256) {
+        const int p = i / pieces, k0 = (i - p * pieces) << 3;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(seg + p * ks + k0), c4 = *reinterpret_cast<const f32x4*>(seg + p * ks + k0 + 4);
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (e < 4 ? a[e] : c4[e - 4]) * K_PLANES_ACT_SCALE;
+            amax = __builtin_fmaxf(amax, __builtin_fabsf(v));
+            nonfinite |= !(v == v);
+            hi[e] = _Float16(v);
+            lo[e] = _Float16(v - float(hi[e]));
+        }
+        _Float16* o = pl + (row0 + p) * 2 * kp + (k0 >> 5) * 64 + (k0 & 31);
+        *reinterpret_cast<f16x8*>(o) = hi;
+        *reinterpret_cast<f16x8*>(o + 32) = lo;
+    }
+    if (py == 0 && grp == 0) {                           // the CLS row of the image: zeros (its value arrives with the pos table)
+        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        _Float16* o = pl + size_t(b) * ntok * 2 * kp;
+        for (int i = threadIdx.x; i < 2 * kp / 8; i += 256) *reinterpret_cast<f16x8*>(o + 8 * i) = z;
+    }
+    pope_range_flag(flag, POPE_RANGE_PATCH, nonfinite || !(amax < POPE_F16_OVERFLOW));
+}
+
 __global__ __launch_bounds__(256) void range_check_kernel(const float* __restrict__ x, size_t n, float scale, unsigned* flag,
                                                            unsigned bit) {
     float amax = 0.f;
@@ -325,6 +391,15 @@ int pope_launch_im2col_planes(const float* img, void* a_planes, int B, int H, in
     if (!img || !a_planes || B <= 0 || patch <= 0 || H % patch || W % patch || (kp & 31) || kp < 3 * patch * patch) return POPE_ERR_ARG;
     const int gw = W / patch, ntok = 1 + (H / patch) * gw;
     const size_t n2 = size_t(B) * ntok * (kp / 2);
+    const size_t strip_lds = size_t(IM2_P) * (kp + 4) * sizeof(float);
+    const int groups = (gw + IM2_P - 1) / IM2_P;
+    const long long strips = (long long)B * (H / patch) * groups;
+    if (!(patch & 1) && strip_lds <= 48 * 1024 && strips < (1ll << 31) && !(reinterpret_cast<uintptr_t>(img) & 7) &&
+        !(reinterpret_cast<uintptr_t>(a_planes) & 15)) {
+        hipLaunchKernelGGL(im2col_planes_strip_kernel, dim3(unsigned(strips)), dim3(256), strip_lds, stream, img,
+                           static_cast<_Float16*>(a_planes), B, H, W, patch, kp, ntok, gw, groups, flag);
+        return pope_check_launch();
+    }
     const unsigned blocks = unsigned(n2 / 256 + 1 < 65536 ? n2 / 256 + 1 : 65536);
     hipLaunchKernelGGL(im2col_planes_kernel, dim3(blocks), dim3(256), 0, stream, img, static_cast<_Float16*>(a_planes), B, H, W,
                        patch, kp, ntok, gw, flag);
