@@ -5,7 +5,7 @@ import json
 import re
 import sys
 
-KERNELS = {"attention": "attn_f16x3_pipe_kernel<true, true>", "gemm_qkv": "gemm_planes16_kernel<0, true, false, false>",
+KERNELS = {"attention": "attn_f16x3_pipe_kernel<true, true, false>", "gemm_qkv": "gemm_planes16_kernel<0, true, false, false>",
            "gemm_fc1_gelu": "gemm_planes16_kernel<1, true, false, false>", "gemm_proj": "gemm_rowln16_kernel<true, false>"}
 src = sys.argv[1]
 blocks, cur = {}, None
