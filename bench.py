@@ -84,10 +84,11 @@ def kernel_flops(kind, chunk):
 
 
 def kernel_bytes(kind, chunk):
-    """Algorithmic HBM bytes of one launch (activations in + out; weights are L2/MALL resident)."""
+    """Algorithmic HBM bytes of one launch (activations in + out; weights are L2/MALL resident).  The LN-fused residual
+    GEMMs (proj, FC2) read the operand planes and the residual and write x AND the next LayerNorm's output planes."""
     rows = chunk * NTOK
-    return 4 * {"attention": rows * 4 * DIM, "gemm_qkv": rows * 4 * DIM, "gemm_proj": rows * 3 * DIM,
-                "gemm_fc1_gelu": rows * (DIM + HIDDEN), "gemm_fc2": rows * (HIDDEN + 2 * DIM),
+    return 4 * {"attention": rows * 4 * DIM, "gemm_qkv": rows * 4 * DIM, "gemm_proj": rows * 4 * DIM,
+                "gemm_fc1_gelu": rows * (DIM + HIDDEN), "gemm_fc2": rows * (HIDDEN + 3 * DIM),
                 "layernorm": rows * 2 * DIM,
                 "patch_embed_gemm": chunk * 3 * H_IMG * W_IMG + rows * DIM}.get(kind, 0)
 
