@@ -373,6 +373,10 @@ def main():
         except Exception as e:  # noqa: BLE001 — reported in place, the headline line stands
             result["pose"] = {"error": f"{type(e).__name__}: {e}"}
         if args.only is None:
+            try:   # BASELINE config 2: extraction only, one 64-image batch
+                result["extract_only"] = bench_legs.extract_only_leg(model, img0, device, chunk=args.chunk)
+            except Exception as e:  # noqa: BLE001
+                result["extract_only"] = {"error": f"{type(e).__name__}: {e}"}
             try:   # the same step publishing conf_matrix [n, L, S] like the reference's CoarseMatching always does (coarse_matching.py:145)
                 pipe.want_conf = True
                 o2 = pipe(img0, img1)

@@ -289,6 +289,33 @@ def pose_leg(pipe, img0, img1, device, steps=3, cpu_baseline=True):
     return r
 
 
+def extract_only_leg(model, img, device, chunk=64, iters=5):
+    """BASELINE config 2: DINOv2 ViT-S/14 feature extraction only, one batch of `chunk` 640x480 crops (centre-cropped to
+    476 x 630) resident in HBM -> final-norm tokens.  images/s, the algorithmic rate against the f16 MFMA peak, and a
+    self-check: images 0 and chunk - 1 of the batch bit-equal to their single-image forwards."""
+    x = img[:chunk].contiguous()
+    npt = (x.shape[2] // 14) * (x.shape[3] // 14)
+    ntok = npt + 1
+    fl = 451584.0 * npt + 12 * (3538944.0 * ntok + 1536.0 * ntok * ntok)      # SURVEY §8a closed form, per image
+    fwd = lambda t: model(t, is_training=True)["x_norm_patchtokens"]          # noqa: E731
+    fwd(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        y = fwd(x)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    ok = bool(torch.isfinite(y).all()) and torch.equal(fwd(x[:1])[0], y[0]) and torch.equal(fwd(x[-1:])[0], y[-1])
+    tf = fl * chunk / ms / 1e9
+    return {"value": round(chunk * 1e3 / ms, 1), "unit": "images/s", "batch": int(chunk), "image": [int(x.shape[2]), int(x.shape[3])],
+            "ms_per_batch": round(ms, 3), "gflop_per_image": round(fl / 1e9, 3), "tflops_algorithmic": round(tf, 1),
+            "frac_of_f16_mfma_peak": round(tf / PEAK_F16_MFMA_TFLOPS, 4),
+            "frac_of_f16_mfma_peak_executed": round(3 * tf / PEAK_F16_MFMA_TFLOPS, 4), "verified": ok,
+            "workload": "BASELINE config 2: ViT-S/14 extraction only, one launch sequence per batch, inputs and outputs in HBM; f16x3"}
+
+
 def attention_ramp_leg(device, chunk=64, ntok=1531, heads=6, iters=10):
     """Data dependence of the dominant kernel, made visible: the lazy-softmax attention redoes a 64-key tile exactly when its
     probabilities leave the f16 range of the running reference (attention_f16x3.hip).  On the bench's synthetic weights that
