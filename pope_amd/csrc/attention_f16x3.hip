@@ -490,8 +490,9 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     //     p' < 2^16 still splits into f16 (hi, lo), and with 2^8 of headroom under the running maximum the split keeps
     //     fp32 accuracy;
     //   * the subtraction: the score MFMAs start from C = -ref (nref), so s - ref is what they deliver.
-    // The tile's probability sum (computed anyway) tells whether that held: any p' >= 65 504 makes it >= 65 504.  Only
-    // then — and for NaN/inf — `redo_tile` recomputes the tile's raw scores from its K stage (still resident) and
+    // The tile's probability sum (computed anyway) tells whether that may have failed: any p' >= 65 504 makes it >= 65 504.
+    // Then the cold path looks at the probabilities themselves, and only for a real overflow — or NaN/inf — `redo_tile`
+    // recomputes the tile's raw scores from its K stage (still resident) and
     // takes the exact pass: true row maximum, new reference, o and l rescaled, and the next tile's scores (already
     // computed against the old reference) shifted to the new one.  Results do not depend on which path ran beyond fp32
     // rounding; the speed does (diffuse attention rows: exact pass on tile 0 only).
@@ -588,7 +589,17 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         return;
 #endif
         const float tile_sum = sm_ls[0] + sm_ls[1];
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(tile_sum < LAZY_LIMIT)) != 0, 0)) redo_tile(tile, st, ptag);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(tile_sum < LAZY_LIMIT)) != 0, 0)) {
+            // the sum of a lane's 32 probabilities is a conservative test (flat rows reach it 5 log2 units early): on this
+            // cold path look at the probabilities themselves (still in c0, c1) and redo only if one left the f16 range
+            const f32x16& c0 = sb[decltype(ptag)::value][0];
+            const f32x16& c1 = sb[decltype(ptag)::value][1];
+            float mt = vmax3(c0[0], c1[0], c0[1]);
+#pragma unroll
+            for (int i = 1; i < 15; ++i) mt = vmax3(mt, c1[i], c0[i + 1]);
+            mt = __builtin_fmaxf(mt, c1[15]);
+            if (__builtin_amdgcn_ballot_w64(!(mt < LAZY_LIMIT) || !(tile_sum == tile_sum)) != 0) redo_tile(tile, st, ptag);
+        }
         l_run += sm_ls;
     };
     // ---- phase 1: S^T(tile in stage st_next) -> (n0, n1), each MFMA followed by a slice of the softmax of (c0, c1)
