@@ -160,6 +160,24 @@ def test_host_sturm_roots_match_planted_roots(host):
     c = np.poly([0.25, 0.25, -0.5])[::-1].copy()
     assert host.host_sturm_roots(ptr(c), 3, -1.0, 1.0, ptr(out)) == 2
     np.testing.assert_allclose(out[:2], [-0.5, 0.25], atol=1e-6)
+    # the device always passes degree 10: leading coefficients that vanish (true degree 7 here) are stripped
+    c = np.zeros(11)
+    c[:8] = np.poly([0.5, -0.25, 0.75, 2.0, -3.0, 1.5, -1.5])[::-1]
+    assert host.host_sturm_roots(ptr(c), 10, -1.0, 1.0, ptr(out)) == 3
+    np.testing.assert_allclose(out[:3], [-0.25, 0.5, 0.75], atol=1e-9)
+    # an even polynomial: every other remainder of the chain loses two degrees at once (division steps of length 3)
+    c = np.polymul(np.polymul([1, 0, -0.25], [1, 0, -0.04]), np.polymul([1, 0, 1.0], [1, 0, 0, 0, 1.0]))[::-1].copy()
+    assert host.host_sturm_roots(ptr(c), len(c) - 1, -1.0, 1.0, ptr(out)) == 4
+    np.testing.assert_allclose(out[:4], [-0.5, -0.2, 0.2, 0.5], atol=1e-9)
+    # the interval is (lo, hi]: a root at hi counts, a root at lo does not (coefficients chosen so that Horner's rule gives
+    # exact zeros at both ends; with rounding noise there the end roots fall on whichever side the noise puts them)
+    c = np.poly([1.0, -1.0, 0.5])[::-1].copy()
+    assert host.host_sturm_roots(ptr(c), 3, -1.0, 1.0, ptr(out)) == 2
+    np.testing.assert_allclose(out[:2], [0.5, 1.0], atol=1e-9)
+    # a constant and the zero polynomial have no roots
+    c = np.zeros(11); c[0] = 3.0
+    assert host.host_sturm_roots(ptr(c), 10, -1.0, 1.0, ptr(out)) == 0
+    assert host.host_sturm_roots(ptr(np.zeros(11)), 10, -1.0, 1.0, ptr(out)) == 0
 
 
 def test_host_samples_identical_to_oracle(host):
