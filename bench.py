@@ -9,6 +9,7 @@ dense dual-softmax / mutual-NN matching of the 1530x1530 descriptor pairs (BASEL
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      # no launcher: starts that same command itself (self_launch)
 
 Pairs are independent: every rank works on its own batch (weak scaling, no data-path collective);
 the only exchange is the RCCL all_gather of per-pair match counts at the end of each step.
@@ -149,6 +150,26 @@ def verify_step(model, img0, img1, out, picks):
     return bad
 
 
+def self_launch(n):
+    """Run `python bench.py --gpus N ...` as N ranks of ONE node: `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` in a child process.  Rank 0's
+    JSON line goes to stdout as it arrives, everything else to stderr; returns the launcher's exit code (non-zero when any
+    rank failed).  Nothing here imports a GPU library or calls HIP."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    for line in proc.stdout:
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,14 +202,33 @@ def main():
     ap.add_argument("--precision", choices=sorted(PRECISION_INFO), default="f16x3",
                     help="arithmetic of the Linear layers, attention and the matcher contraction (both are held to the "
                          "same parity tests)")
+    ap.add_argument("--launch-selftest", choices=["ok", "fail"], default=None,
+                    help="dev: the ranks only rendezvous over gloo on the CPU and rank 0 prints a stub line (\"fail\": rank 1 "
+                         "exits non-zero) — tests the launch / relay / exit-code path of `bench.py --gpus N` without a GPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: start the N ranks ourselves.  This parent must never touch the
+        # GPU (a process that has initialised HIP cannot hand the card to children cleanly): it only spawns
+        # torch.distributed.run, relays the ranks' output and passes the exit code on.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size must equal --gpus")
     import torch.distributed as dist
+    if args.launch_selftest:
+        dist.init_process_group(backend="gloo")
+        got = [None] * world
+        dist.all_gather_object(got, rank)
+        if args.launch_selftest == "fail" and rank == world - 1:
+            raise SystemExit(3)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"selftest": True, "n_gpus": world, "ranks_seen": got}), flush=True)
+        dist.destroy_process_group()
+        return
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)

@@ -902,6 +902,9 @@ int pope_launch_gemm_nt_f16x3_planes(const GemmParams& g, hipStream_t stream) {
     // the epilogue addresses C (and res) through 32-bit buffer offsets
     if (size_t(g.M + 256) * g.ldc * 4 >= (size_t(1) << 32) - 512) return POPE_ERR_ARG;
     if (g.epilogue == EPI_BIAS_LS_RES && size_t(g.M + 256) * g.ldres * 4 >= (size_t(1) << 32) - 512) return POPE_ERR_ARG;
+#ifdef POPE_XSTAT_LAB   // lab builds only (scripts/xstat_ab.sh): the X-stationary mainloop of scripts/gemm_xstat_lab.hip for QKV / FC1
+    if (pope_xstat_supported(g)) return pope_launch_xstat(g, stream);
+#endif
     switch (g.epilogue) {
         case EPI_BIAS: return out_planes ? launch_planes<EPI_BIAS, true>(g, stream) : launch_planes<EPI_BIAS, false>(g, stream);
         case EPI_BIAS_GELU:

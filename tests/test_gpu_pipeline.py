@@ -44,3 +44,26 @@ def test_streams_bit_equal_to_single_stream_on_a_fresh_model(dev, sd0, precision
     for k in ("feat0", "feat1", "i_ids", "j_ids", "mconf"):
         assert torch.equal(again[k], want[k]), k
     assert multi.reruns == 0 and multi.model.overflow_events == 0
+
+
+def test_bench_gpus_2_without_launcher(dev):
+    """`python bench.py --gpus 2 ...` exactly as the driver would call it — no torch.distributed.run in front — must start
+    its two ranks itself and print ONE line with n_gpus 2.  On this one-GPU box both ranks share cuda:0
+    (`--rehearse-on-one-gpu`: gloo collectives on CPU copies); the N-rank code path — sharded inputs, per-rank step, the
+    gather of match counts, barrier + MAX over ranks — is the one an 8-GPU node runs over RCCL.  Two child processes on
+    the card (the pool allows six)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                          "--pairs", "4", "--chunk", "4", "--rehearse-on-one-gpu", "--no-kernel-table"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak"
+    assert line["verified"] is True and line["value"] > 0

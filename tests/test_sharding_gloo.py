@@ -132,3 +132,31 @@ def test_walk_pair_list_world2_gloo_unequal_shards(n_pairs, batch):
     assert all(hi - lo <= batch for spans in (got[0][1], got[1][1]) for lo, hi in spans)
     if n_pairs == 1001:   # 501 + 500 pairs: both shards end in a ragged batch, of different sizes
         assert got[0][1][-1] == (384, 501) and got[1][1][-1] == (885, 1001)
+
+
+def _run_bench(*flags):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags], capture_output=True, text=True, env=env,
+                          timeout=300, cwd=root)
+
+
+def test_bench_gpus_2_launches_itself():
+    """`python bench.py --gpus 2` with NO launcher must start its own two ranks (the driver calls it the way it calls
+    `--gpus 1`), relay exactly rank 0's line and exit 0.  `--launch-selftest` keeps the ranks on gloo / CPU: the GPU twin of
+    this test is tests/test_gpu_pipeline.py::test_bench_gpus_2_without_launcher."""
+    import json
+    res = _run_bench("--gpus", "2", "--launch-selftest", "ok")
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1]
+
+
+def test_bench_self_launch_propagates_a_rank_failure():
+    res = _run_bench("--gpus", "2", "--launch-selftest", "fail")
+    assert res.returncode != 0
+    assert not [ln for ln in res.stdout.splitlines() if ln.strip()]
