@@ -392,7 +392,8 @@ int pope_crop_warp_u8(const unsigned char* img_hwc, int H, int W, int C, const d
  * Outputs: R [B, 9], t [B, 3] (unit norm), E [B, 9] fp64; inliers [M] bytes (RANSAC inlier AND in front of both cameras,
  * the mask recoverPose leaves behind); info [B, 8] int32 = {n_inliers of the returned pose — 0 means `None` (fewer than five
  * matches, no model with five inliers, or no point in front of both cameras) —, RANSAC inliers, hypotheses tried, rounds,
- * winning hypothesis, winning root, matches of the pair, status (-1: counts exceed M)}.
+ * winning hypothesis, winning root, matches of the pair, status (-1: refused — the counts up to and including this pair exceed
+ * M, or one of them is negative)}.  Rows of `inliers` past sum(counts) are not written.
  * The minimal samples of hypothesis h come from a counter-based hash of (seed, h): results do not depend on the batch a
  * pair rides in.  cv2's own random stream is not reproducible without cv2 (absent here): parity with OpenCV is unpinned,
  * the checker is oracle/pose_ref.py (same algorithm, same samples, numpy fp64).

@@ -156,6 +156,61 @@ def gen_loftr():
                  hw1_f=np.array(data["hw1_f"]))
 
 
+def gen_loftr_large():
+    """tests/golden/loftr_512_peaked.npz: the reference Matcher at the OnePose drivers' shape (eval_onepose_json.py:88: 512 x
+    512, L = S = 4 096) under the `peaked` synthetic weights (pope_amd/synth.py:peaked_matcher_state_dict — the common-mode
+    component of the coarse features projected out, so that the matcher publishes thousands of confident matches as a
+    trained checkpoint does), default threshold 0.2.  Strided taps, the full match list, and the calibration mean that
+    pins the weights bit for bit on other hosts."""
+    from oracle import loftr_ref
+    from pope_amd.matcher import default_cfg as my_cfg
+
+    def pre(sd_, img):
+        with torch.no_grad():
+            return loftr_ref.resnet_fpn_8_2(sd_, img)[0]
+
+    sd = synth.peaked_matcher_state_dict(pre, seed=0)
+    mean = sd.pop("_calibration_mean")
+    again = synth.peaked_matcher_state_dict(mean, seed=0)
+    again.pop("_calibration_mean")
+    assert all(torch.equal(sd[k], again[k]) for k in sd)          # the mean alone reproduces the weights
+    digest = sd_digest({k: v for k, v in sd.items() if v.dtype.is_floating_point})
+    n, s0, thr, name = 1, (512, 512), 0.2, "loftr_512_peaked"
+    i0, i1 = synth.synthetic_gray_pairs(n, *s0, seed=23)
+    ref, cfg = load_reference_matcher({"thr": thr})
+    ref.load_state_dict({"matcher." + k: v.clone() for k, v in sd.items()}, strict=True)
+    data = {"image0": i0, "image1": i1}
+    with torch.no_grad():
+        ref(data)
+        fc0, fc1 = ref({"image0": i0, "image1": i1}, only_att_fea=True)
+        bc, bf = ref.backbone(torch.cat([i0, i1], 0))
+        mine = loftr_ref.matcher_forward(sd, my_cfg, i0, i1)
+        mbc, mbf = loftr_ref.resnet_fpn_8_2(sd, torch.cat([i0, i1], 0))
+    d = {"backbone_c": maxdiff(bc, mbc), "backbone_f": maxdiff(bf, mbf), "feat_c0": maxdiff(fc0, mine["feat_c0"]),
+         "feat_c1": maxdiff(fc1, mine["feat_c1"]), "conf": maxdiff(data["conf_matrix"], mine["conf_matrix"])}
+    for k in ("b_ids", "i_ids", "j_ids"):
+        assert torch.equal(data[k], mine[k]), k
+    for k in ("mconf", "mkpts0_c", "mkpts1_c", "mkpts0_f", "mkpts1_f", "expec_f"):
+        d[k] = maxdiff(data[k], mine[k])
+    print(name, "matches", len(data["b_ids"]), "of which mconf > 0.9:", int((data["mconf"] > 0.9).sum()),
+          "oracle-vs-reference:", {k: f"{v:.1e}" for k, v in d.items()})
+    assert max(d.values()) <= 1e-5 and len(data["b_ids"]) > 2000, d
+    conf = data["conf_matrix"]
+    np.savez(os.path.join(OUT, name + ".npz"), weights_seed=0, weights_digest=digest, outconv_mean=mean.numpy(),
+             thr=np.float64(thr), n=n, shape0=np.array(s0), shape1=np.array(s0),
+             image_digest=np.array([float(i0.double().sum()), float(i1.double().sum())]),
+             backbone_c=bc[:, ::4, ::4, ::4].numpy(), backbone_f=bf[:, ::8, ::16, ::16].numpy(),
+             feat_c0=fc0[:, ::16].numpy(), feat_c1=fc1[:, ::16].numpy(),
+             conf_rowmax=conf.max(2)[0].numpy(), conf_rowarg=conf.max(2)[1].numpy().astype(np.int32),
+             conf_colmax=conf.max(1)[0].numpy(), conf_colarg=conf.max(1)[1].numpy().astype(np.int32),
+             conf_sum=np.array([float(conf.double().sum())]),
+             b_ids=data["b_ids"].numpy().astype(np.int32), i_ids=data["i_ids"].numpy().astype(np.int32),
+             j_ids=data["j_ids"].numpy().astype(np.int32), mconf=data["mconf"].numpy(),
+             mkpts1_f=data["mkpts1_f"].numpy(), expec_f=data["expec_f"].numpy(),
+             hw0_c=np.array(data["hw0_c"]), hw1_c=np.array(data["hw1_c"]), hw0_f=np.array(data["hw0_f"]),
+             hw1_f=np.array(data["hw1_f"]))
+
+
 def gen_driver():
     """tests/golden/driver_pair.npz: the drivers' per-pair step (eval_linemod_json.py:65-127,150) executed with the
     reference's own DINOv2 and Matcher modules on synthetic proposals (SAM / cv2 are not run: SURVEY.md §8 a-18)."""
@@ -374,6 +429,8 @@ def main():
         return gen_vit_archs()
     if "--only-sam" in sys.argv:   # optionally followed by case names
         return gen_sam_encoder([a for a in sys.argv[sys.argv.index("--only-sam") + 1:] if not a.startswith("-")])
+    if "--only-loftr-large" in sys.argv:
+        return gen_loftr_large()
     if "--only-loftr" in sys.argv:
         return gen_loftr()
     if "--only-driver" in sys.argv:
@@ -486,6 +543,7 @@ def main():
     np.savez(os.path.join(OUT, "top3.npz"), ref=ref.numpy(), fea=fea.numpy(), scores=scores.numpy(),
              slot_scores=slots, slot_index=np.array(top))
     gen_loftr()
+    gen_loftr_large()
     gen_driver()
     gen_pair_lists()
     gen_vit_archs()

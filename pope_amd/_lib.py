@@ -211,6 +211,25 @@ def params_key(tensors):
     return tuple((t.data_ptr(), t._version) for t in tensors)
 
 
+def param_slots(module, buffers=False):
+    """Where a module tree keeps its parameters (and buffers): [(the owning submodule's `_parameters` / `_buffers` dict, name)].
+    Cached by the models as the source list of their derived data; the TENSORS are looked up through it on every call
+    (`slots_key`), so a replaced Parameter object — `load_state_dict(..., assign=True)`, `m.weight = nn.Parameter(..)`,
+    `.to()` — is seen like an in-place edit, at the price of one dict lookup per tensor instead of a walk over the module
+    tree (0.35 ms for ViT-S/14).  Adding or removing SUBMODULES after the first call is not tracked."""
+    slots = []
+    for m in module.modules():
+        slots += [(m._parameters, n) for n in m._parameters]
+        if buffers:
+            slots += [(m._buffers, n) for n in m._buffers]
+    return slots
+
+
+def slots_key(slots):
+    """`params_key` of the tensors currently sitting in `slots` (None entries, e.g. `bias=None`, keyed as such)."""
+    return tuple((t.data_ptr(), t._version) if t is not None else None for t in (d.get(n) for d, n in slots))
+
+
 def ptr(t):
     """Device pointer of a contiguous fp32/int tensor (or None)."""
     if t is None:

@@ -30,11 +30,7 @@ constexpr int KST = 72;   // K plane row stride (halves): 144 B = 9 x 16 B (odd)
 constexpr int VST = 96;   // V plane row stride (halves): 192 B -> the 4 rows of a ds_read_b64_tr_b16 block hit disjoint banks
 // + 32 halves: the lo plane starts 16 banks after the hi plane, so the eight lanes that copy one 128-byte planes chunk
 // (4 hi pieces + 4 lo pieces) into LDS hit 32 different store banks (without it: a 2-way conflict on every ds_write_b128)
-#ifdef ATTN_NO_PLANE_PAD
-constexpr int K_PLANE = KT * KST, V_PLANE = KT * VST;
-#else
 constexpr int K_PLANE = KT * KST + 32, V_PLANE = KT * VST + 32;
-#endif
 constexpr size_t X3_ATTN_STAGE_BYTES = size_t(2) * (K_PLANE + V_PLANE) * sizeof(_Float16);  // 43 008 B
 constexpr int OST = 68;   // epilogue staging row (floats)
 constexpr size_t X3_ATTN_EPI_BYTES = size_t(32) * 8 * OST * sizeof(float);  // O^T transpose staging, 32 rows per wave
@@ -542,9 +538,6 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     // four pairs in front of the first MFMA, under the latency of its K fragments; 2, 3 or 6 pairs behind every 4th,
     // 6th or 12th MFMA; both halves of a P split behind one MFMA — all 0.5 to 2 % slower than the even spread.)
     auto softmax_slice = [&](int slot, auto ptag) __attribute__((always_inline)) {
-#ifdef ATTN_ABL_NOSOFTMAX  // dev ablation (wrong results): what the phase costs without its VALU work
-        return;
-#endif
         if (slot == 0) sm_ls = f32x2{0.f, 0.f};
         if (slot % 3 != 2)
             exp_pair((slot / 3) * 2 + slot % 3, sb[decltype(ptag)::value][0], sb[decltype(ptag)::value][1], std::true_type{});
@@ -585,9 +578,6 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     };
     // after the fast pass of a tile: did every probability fit?  (wave-uniform branch; !(x < limit) also catches NaN)
     auto settle = [&](int tile, int st, auto ptag) __attribute__((always_inline)) {
-#ifdef ATTN_ABL_NOSOFTMAX
-        return;
-#endif
         const float tile_sum = sm_ls[0] + sm_ls[1];
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(tile_sum < LAZY_LIMIT)) != 0, 0)) {
             // the sum of a lane's 32 probabilities is a conservative test (flat rows reach it 5 log2 units early): on this
@@ -657,14 +647,10 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
             if (j == 4) o0 = mfma_f16(vh[cur][0], ph, o0);
             if (j == 5) o1 = mfma_f16(vh[cur][1], ph, o1);
             if (j == 2 && g < 3) { vl[0] = vfrag(Vl, u, s2, 0); vl[1] = vfrag(Vl, u, s2, 1); }
-#ifdef ATTN_ABL_NOSPLIT
-            if (j == 1) { h0[nxt] = h0[cur]; l0[nxt] = l0[cur]; h1[nxt] = h1[cur]; l1[nxt] = l1[cur]; }
-#else
             if (g < 3) {
                 if (j == 1) split_group(g + 1, 0, h0[nxt], l0[nxt], ptag);
                 if (j == 3) split_group(g + 1, 1, h1[nxt], l1[nxt], ptag);
             }
-#endif
             if (SPLIT_KV && j == 5) {  // a quarter of tile t+2's staging per 16-key group
                 if constexpr (IN_PLANES) {
                     write_chunk(st_write, g, pregs);
@@ -732,9 +718,7 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         if constexpr (IN_PLANES) load_planes(t + 4, regs);
         else if (t + 3 < nkt) load_kv(t + 3);
         ATTN_STAMP(t, 2);
-#ifndef ATTN_ABL_NOBAR
         __syncthreads();  // tile t+2 is published; every wave is done with stage st_cur
-#endif
         ATTN_STAMP(t, 3);
         rotate();
         ++t;
@@ -817,17 +801,9 @@ static int launch_attn_x3(const float* qkv, float* out, int B, int N, int heads,
     if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return POPE_ERR_ARG;
     if (size_t(N) * 3 * heads * HD * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
     const dim3 grid(unsigned((N + QB - 1) / QB) * heads * B);
-    static const bool pipe = !getenv("POPE_ATTN_NO_PIPE");  // dev switch: the un-pipelined kernel, for A/B runs
-    if (pipe) {
-        static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
-        if (!pope_opt_in_lds(attn_f16x3_pipe_kernel<OUT_PLANES, false>, X3_ATTN_PIPE_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
-        hipLaunchKernelGGL((attn_f16x3_pipe_kernel<OUT_PLANES, false>), grid, dim3(NT), X3_ATTN_PIPE_BYTES, stream, qkv, out, N, heads);
-        return pope_check_launch();
-    }
-    constexpr size_t lds = X3_ATTN_STAGE_BYTES > X3_ATTN_EPI_BYTES ? X3_ATTN_STAGE_BYTES : X3_ATTN_EPI_BYTES;
     static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
-    if (!pope_opt_in_lds(attn_f16x3_kernel<OUT_PLANES>, lds, lds_ok)) return POPE_ERR_LAUNCH;
-    hipLaunchKernelGGL(attn_f16x3_kernel<OUT_PLANES>, grid, dim3(NT), lds, stream, qkv, out, N, heads);
+    if (!pope_opt_in_lds(attn_f16x3_pipe_kernel<OUT_PLANES, false>, X3_ATTN_PIPE_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
+    hipLaunchKernelGGL((attn_f16x3_pipe_kernel<OUT_PLANES, false>), grid, dim3(NT), X3_ATTN_PIPE_BYTES, stream, qkv, out, N, heads);
     return pope_check_launch();
 }
 

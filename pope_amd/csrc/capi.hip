@@ -281,18 +281,16 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
     void* hid_pl = hid;
     // Fused form (dim 384): every residual GEMM (patch embed, proj, fc2) also emits the LayerNorm that follows it —
     // as planes for the next GEMM, or as fp32 x_norm after the last block — so no stand-alone LayerNorm launch is left
-    // (gemm_rowln.hip).  POPE_NO_ROWLN=1: dev switch for A/B runs against the unfused sequence.
-    static const bool no_rowln = getenv("POPE_NO_ROWLN") && atoi(getenv("POPE_NO_ROWLN"));
+    // (gemm_rowln.hip).
     GemmParams probe = {};
     probe.M = rows; probe.N = dim; probe.K = dim; probe.lda = dim; probe.ldw = dim; probe.ldc = dim; probe.ldres = dim;
-    const bool fusable = planes && !plain && w->patch_wp && !no_rowln && pope_gemm_rowln_supported(probe);
+    const bool fusable = planes && !plain && w->patch_wp && pope_gemm_rowln_supported(probe);
     // Small batches: the full-row-tile kernel has one tile per 128 rows, each a serial chain of K / 32 K-steps + a 23 us
     // epilogue; while the 128 x 128 residual GEMM still fits ONE round of its 2 x CUs workgroup slots (3 column tiles per row
     // tile) it finishes sooner, and `layernorm_rowln_order` reproduces the fused epilogue's LayerNorm bit for bit — an image
     // gives the same tokens alone (this path) and inside a 64-image chunk (fused path).  Driver step (9 images of 196 x
     // 196): proj 38 -> ~25 us, FC2 105 -> ~70 us per launch.
-    static const bool no_small = getenv("POPE_ROWLN_ALWAYS") && atoi(getenv("POPE_ROWLN_ALWAYS"));   // dev A/B switch
-    const bool small = fusable && !no_small && 3 * ((rows + 127) / 128) <= 2 * pope_cu_count();
+    const bool small = fusable && 3 * ((rows + 127) / 128) <= 2 * pope_cu_count();
     const bool fused = fusable && !small;
     // plain GEMM over the token rows: C (fp32) or c_f16 (f16 row-major) = epi(a_f16 . w_f16^T + bias [...])
     auto plain_gemm = [&](const void* a_f16, const void* w_f16, const float* bias, float* Cf, void* c_f16, int N, int K, int epi,

@@ -1,12 +1,14 @@
-// f16x3 "planes" NT GEMM on v_mfma_f32_16x16x32_f16 (the round-2 mainloop of every Linear layer and of the dense
-// matcher's contraction).  Same contract, operand layout, persistent tile stream, staging and epilogues as the
-// 32x32x16 kernel of gemm_f16x3.hip (kept as the A/B reference: POPE_GEMM_MFMA=32) — what changes is the MFMA shape:
+// f16x3 "planes" NT GEMM on v_mfma_f32_16x16x32_f16: the mainloop of every Linear layer, of the LoFTR convolutions and of
+// the dense matcher's contraction.  Contract: operands are f16 hi/lo planes written once by their producer (LayerNorm, a GELU
+// epilogue, the weight loader), so the K loop is loads -> ds_write_b128 -> ds_read_b128 -> MFMA with no VALU work; persistent
+// tile stream; LDS-transposed coalesced epilogues.  Why this MFMA shape (round 2; a 32x32x16 twin of this kernel existed
+// until round 4 as an A/B reference and was deleted with the other dev switches):
 //   * measured on this chip (scripts/mfma_shape_lab2.hip: this K-step on random operands re-read from LDS): the
 //     16x16x32 form needs the same cycles per FLOP but the chip holds 1.90 GHz under it instead of 1.67 GHz under
 //     the 32x32x16 form -> 1 871 vs 1 651 TFLOP/s executed (+13 %); MI355X_MICROARCH.md "DVFS give-back" item 7;
 //   * its C^T accumulator block gives a lane FOUR CONSECUTIVE output columns of one row, so the epilogue's LDS
 //     transposition writes 16-byte pieces.
-// A wave owns 64 x 64 of the 128 x 128 tile as 4 x 4 blocks of 16 x 16 (64 accumulator registers, as before); one
+// A wave owns 64 x 64 of the 128 x 128 tile as 4 x 4 blocks of 16 x 16 (64 accumulator registers); one
 // K-step (32) is ONE k-step of the MFMA: 16 fragment reads (ds_read_b128) feed 48 MFMAs (16 per partial product).
 // LDS rows are 160 bytes ([32 hi | 32 lo] halves + 32 B pad): conflict-free for the 16-row x 4-chunk fragment
 // reads; two stages x 256 rows = 80 KB per workgroup, two workgroups per CU = all 160 KB.
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
     // offset (tap * chunks + chunk: the folded matrices keep their tap-major columns) is its own counter.
     int cv_chunk = 0, cv_dx = 0, cv_off = 0, cv_dyi = 0, cv_w = 0;
 
-    // Tile stream of this persistent workgroup (gemm_f16x3.hip has the measurements behind every choice here): full
+    // Tile stream of this persistent workgroup (DESIGN.md findings 5-7 have the measurements behind every choice here): full
     // rounds by XCD-remapped id, the partial last round one tile per CU by raw blockIdx; the K-steps of consecutive
     // tiles are ONE stream (item = (tile, kt)) through the double-buffered LDS, two register sets of loads in flight.
     // The bookkeeping uses asm selects: a K-step must stay ONE basic block for the pinned instruction mix.
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
     };
 
     // Epilogue of one tile: branch-free, no loads between its stores (bias / gamma hoisted; rows >= M and columns >= N
-    // dropped by the buffer range check; residual rows fetched eight at a time): gemm_f16x3.hip, finding 7 of DESIGN.md.
+    // dropped by the buffer range check; residual rows fetched eight at a time): finding 7 of DESIGN.md.
     auto epilogue = [&](int tile, float* epi) {
         if constexpr (EPI == EPI_SIM) {
             // Similarity tile of batch b: sim = acc / divisor_eff (divisor_eff = T * 2^16: the operand scales are exact

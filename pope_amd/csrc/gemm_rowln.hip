@@ -104,37 +104,6 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
     const unsigned va = unsigned(prow) * unsigned(g.lda) * 4u + pc * 16u, vw = unsigned(prow) * unsigned(g.ldw) * 4u + pc * 16u;
     const unsigned a64 = 64u * unsigned(g.lda) * 4u, w64 = 64u * unsigned(g.ldw) * 4u;
     u32x4 r0[NLD];  // A rows, then W rows: the K-step after the one in the other LDS stage
-#ifdef RL_DMA_W   // dev experiment: the W rows (6 of the 8 pieces) through LDS-direct loads, A on the register path
-    int w_kt = 0;
-    const unsigned vw_sw = unsigned(prow) * unsigned(g.ldw) * 4u + unsigned(pc ^ (prow & 7)) * 16u;
-    auto dma_w = [&](int stage) {
-        _Float16* S = lds + stage * STAGE_H + (RM + 8 * wave) * ROWB;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_ptr)(S + 64 * i * ROWB), 16, vw_sw, unsigned(w_kt) * 128u + i * w64, 0, 0);
-        w_kt = pope_uniform_select(++w_kt == nk, 0, w_kt);
-    };
-#endif
-#ifdef RL_DMA_A
-    // Mixed staging: the A rows (2 of the 8 pieces per thread and K-step) go straight into LDS (buffer_load ... lds: no
-    // register, no ds_write), the W rows keep the register path.  A wave's 64 lanes fill 1 KB of contiguous LDS = eight
-    // 128-byte rows; the 16-byte chunk swizzle (chunk c of row r at position c ^ (r & 7)) is applied on the SOURCE side:
-    // the lane at position p of row r fetches chunk p ^ (r & 7).
-    int a_ord = 0, a_tile = first, a_kt = 0;
-    const unsigned va_sw = unsigned(prow) * unsigned(g.lda) * 4u + unsigned(pc ^ (prow & 7)) * 16u;
-    auto dma_a = [&](int stage) {
-        const int lt = a_tile < n_tiles ? a_tile : n_tiles - 1;
-        const unsigned sa = unsigned(lt) * unsigned(RM) * unsigned(g.lda) * 4u + unsigned(a_kt) * 128u;
-        _Float16* S = lds + stage * STAGE_H + (8 * wave) * ROWB;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(S + 64 * i * ROWB), 16, va_sw, sa + i * a64, 0, 3);
-        const int wrap = ++a_kt == nk;
-        a_kt = pope_uniform_select(wrap, 0, a_kt);
-        a_ord += wrap;
-        a_tile = tile_of(a_ord);
-    };
-#endif
     int ld_ord = 0, ord = 0;
     int ld_tile = first, ld_kt = 0;
     auto load_next = [&]() {
@@ -143,14 +112,10 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
         // A rows are read exactly once per launch (a tile spans all 384 columns): sc0 + nt keeps the 150 - 600 MB stream
         // from displacing x / xn, which the next kernels re-read (+0.8 % on the step; the same hint on the residual
         // loads, the x stores or the xn stores costs 1 - 10 %: measured, left at the default policy)
-#if !defined(RL_ABL_NOLOAD_A) && !defined(RL_DMA_A)   // dev ablations (wrong results; scripts/ab_rowln.sh): which operand's loads cost the K-step what
 #pragma unroll
         for (int i = 0; i < 2; ++i) r0[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, sa + i * a64, 3);
-#endif
-#if !defined(RL_ABL_NOLOAD_W) && !defined(RL_DMA_W)
 #pragma unroll
         for (int i = 0; i < 6; ++i) r0[2 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, sw + i * w64, 0);
-#endif
         const int wrap = ++ld_kt == nk;
         ld_kt = pope_uniform_select(wrap, 0, ld_kt);
         ld_ord += wrap;
@@ -160,14 +125,10 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
     const int wr_off = prow * ROWB + 8 * (pc ^ (prow & 7));   // rows prow + 64 i: same r & 7
     auto write_stage = [&](int s) {
         _Float16* S = lds + s * STAGE_H + wr_off;
-#ifndef RL_DMA_A
 #pragma unroll
         for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(S + 64 * i * ROWB) = r0[i];
-#endif
-#ifndef RL_DMA_W
 #pragma unroll
         for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(S + (RM + 64 * i) * ROWB) = r0[2 + i];
-#endif
     };
     // fragment t: rows 16 t + l15 of this wave's rows, logical chunk plane * 4 + q4
     const int sw_hi = 8 * (q4 ^ (l15 & 7)), sw_lo = 8 * ((4 + q4) ^ (l15 & 7));
@@ -335,12 +296,6 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
     };
 
     // prologue: item 0 -> LDS stage 0; item 1 in flight
-#ifdef RL_DMA_A
-    dma_a(0);
-#endif
-#ifdef RL_DMA_W
-    dma_w(0);
-#endif
     load_next();
     write_stage(0);
     load_next();
@@ -351,12 +306,6 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
 
     auto item = [&](int s) {
         const _Float16* S = lds + (s & 1) * STAGE_H;
-#ifdef RL_DMA_A
-        dma_a((s + 1) & 1);   // the A rows of item s + 1 into the stage nobody reads during this K-step
-#endif
-#ifdef RL_DMA_W
-        dma_w((s + 1) & 1);
-#endif
         // ni-major: the A fragments (hi, lo: 8 x 4 registers) stay for the K-step, the W fragments stream through two at
         // a time (lo, hi of column block ni), each feeding 12 MFMAs — 48 fragment registers instead of 80 (the kernel
         // sits at the 256-register line: 96 accumulators + 32 staging).  Per accumulator the order of the partial
@@ -383,22 +332,8 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
             // are loaded for almost a whole K-step — except across a tile seam: the epilogue needs those registers (with
             // them live it spills, and a spill reload drains vmcnt, i.e. waits for every load in flight), so the seam
             // load is issued after the epilogue and still has four column groups of MFMAs to arrive
-#if defined(RL_ABL_SPREADW)   // dev ablation: the eight LDS stores spread over the six column groups instead of one burst
-            {
-                constexpr int first_piece[7] = {0, 1, 3, 4, 6, 7, 8};
-                _Float16* Sw = lds + ((s + 1) & 1) * STAGE_H + wr_off;
-#pragma unroll
-                for (int q = first_piece[ni]; q < first_piece[ni + 1]; ++q) {
-                    if (q < 2) *reinterpret_cast<u32x4*>(Sw + 64 * q * ROWB) = r0[q];
-                    else *reinterpret_cast<u32x4*>(Sw + (RM + 64 * (q - 2)) * ROWB) = r0[q];
-                }
-            }
-#elif !defined(RL_ABL_NOWRITE)   // dev ablations (wrong results; scripts/ab_rowln.sh): what the staging costs a K-step
             if (ni == 4) write_stage((s + 1) & 1);
-#endif
-#ifndef RL_ABL_NOLOAD
             if (ni == 5 && kt + 1 != nk) load_next();
-#endif
             if constexpr (!RES_TABLE)
                 if (ni == 2 && g.rl_prefetch && pf_step > 0 && kt % pf_step == 0 && kt / pf_step < 3) prefetch_res(tile, kt / pf_step);
 #pragma unroll
@@ -449,8 +384,7 @@ bool pope_gemm_rowln_supported(const GemmParams& g) {
 // x = res + gamma * (A.W^T + bias) -> g.C (fp32, may alias res), LayerNorm(x; ln_w, ln_b, ln_eps) -> g.ln_planes or g.ln_f32
 int pope_launch_gemm_rowln(const GemmParams& g_in, hipStream_t stream) {
     GemmParams g = g_in;
-    static const int prefetch = [] { const char* e = getenv("POPE_RL_PREFETCH"); return e ? atoi(e) : 1; }();   // dev A/B switch
-    g.rl_prefetch = prefetch;
+    g.rl_prefetch = 1;   // touch the tile's residual lines during its K loop (finding 21: proj -3 %)
     if (!g.a_pl || !g.w_pl || !g.C || !g.res || !g.ln_w || !g.ln_b || (!g.ln_planes) == (!g.ln_f32) || g.M <= 0) return POPE_ERR_ARG;
     if (!pope_gemm_rowln_supported(g)) return POPE_ERR_ARG;
     if (g.res_mod < 0 || (g.res_mod == 0 && !g.gamma)) return POPE_ERR_ARG;

@@ -42,7 +42,7 @@ struct GemmParams {
     int ncb, nrb, ldp;
     float divisor_eff, rdiv;
     int res_mod;         // > 0: the residual row is (row % res_mod) of a [res_mod, ldres] table (patch embed: pos + bias)
-    // f16x3 "planes" operands (gemm_f16x3.hip, planes kernel): a tensor X[rows, ld] kept as two f16
+    // f16x3 "planes" operands (gemm_planes.hip): a tensor X[rows, ld] kept as two f16
     // planes with X = (hi + lo) / scale (power-of-two scale: activations 8, weights 256).  The planes
     // kernel needs a_pl and w_pl; when c_pl is set its epilogue writes planes (scale 8) instead of fp32 C.
     // Layout of a planes tensor [rows, ld]: row-major, 2*ld halves per row, per 32-column chunk the
@@ -99,10 +99,6 @@ int pope_launch_sim_f16x3_planes(const GemmParams& g, hipStream_t stream);  // E
 // residual GEMM + the following LayerNorm in one kernel (gemm_rowln.hip; N = 384 only: `supported` says)
 bool pope_gemm_rowln_supported(const GemmParams& g);
 int pope_launch_gemm_rowln(const GemmParams& g, hipStream_t stream);
-#ifdef POPE_XSTAT_LAB   // lab builds only: scripts/gemm_xstat_lab.hip (a measured negative result, DESIGN.md finding 29)
-bool pope_xstat_supported(const GemmParams& g);
-int pope_launch_xstat(const GemmParams& g, hipStream_t stream);
-#endif
 // the v_mfma_f32_16x16x32_f16 mainloop (gemm_planes.hip) behind both of the above; arguments already validated
 int pope_launch_planes16(const GemmParams& g, hipStream_t stream);
 constexpr float K_PLANES_ACT_SCALE = 8.0f, K_PLANES_W_SCALE = 256.0f;  // == POPE_PLANES_*_SCALE of pope_hip.h

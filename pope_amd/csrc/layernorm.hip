@@ -394,7 +394,9 @@ int pope_launch_im2col_planes(const float* img, void* a_planes, int B, int H, in
     const size_t strip_lds = size_t(IM2_P) * (kp + 4) * sizeof(float);
     const int groups = (gw + IM2_P - 1) / IM2_P;
     const long long strips = (long long)B * (H / patch) * groups;
-    if (!(patch & 1) && strip_lds <= 48 * 1024 && strips < (1ll << 31) && !(reinterpret_cast<uintptr_t>(img) & 7) &&
+    // patch >= 8: the strip kernel advances (dy, channel) by up to 8 segments per pass with ONE wrap (DINOv2: 14, SAM: 16);
+    // smaller patches take the element-wise kernel below
+    if (!(patch & 1) && patch >= 8 && strip_lds <= 48 * 1024 && strips < (1ll << 31) && !(reinterpret_cast<uintptr_t>(img) & 7) &&
         !(reinterpret_cast<uintptr_t>(a_planes) & 15)) {
         hipLaunchKernelGGL(im2col_planes_strip_kernel, dim3(unsigned(strips)), dim3(256), strip_lds, stream, img,
                            static_cast<_Float16*>(a_planes), B, H, W, patch, kp, ntok, gw, groups, flag);

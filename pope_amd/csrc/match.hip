@@ -12,7 +12,7 @@
 // features (C=256).
 //
 // Structure (round 2): the L x S matrix is written ONCE (sim, by the contraction) and read ONCE:
-//   1. contraction on the matrix cores (f16x3 planes GEMM, gemm_f16x3.hip EPI_SIM) whose epilogue also emits the
+//   1. contraction on the matrix cores (f16x3 planes GEMM, gemm_planes.hip EPI_SIM) whose epilogue also emits the
 //      per-tile pieces of the row and column softmax statistics from its registers; `combine_*_kernel` folds the
 //      pieces (KBs per pair).  [fp32 mode: sim_kernel on the fp32 MFMA + two streaming statistics passes.]
 //   2. conf_pass_kernel: one streaming pass that forms conf = softmax_dim1 * softmax_dim2, optionally publishes it in

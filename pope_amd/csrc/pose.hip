@@ -38,18 +38,25 @@ __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
     __shared__ double s_E[10][9];          // candidates handed to recoverPose (1 after RANSAC, <= 10 for the minimal problem)
     __shared__ double s_R1[9], s_R2[9], s_t[3];
     __shared__ unsigned long long s_key;
-    __shared__ int s_off, s_ncand, s_good[4], s_total;
+    __shared__ int s_off, s_ncand, s_good[4], s_total, s_badprefix;
     const int b = blockIdx.x, tid = threadIdx.x;
 #ifdef POSE_STAMPS
     __shared__ unsigned long long stamps[8];
 #endif
     POSE_STAMP(0);
-    if (tid == 0) { s_off = 0; s_key = 0ull; s_ncand = 0; }
+    if (tid == 0) { s_off = 0; s_key = 0ull; s_ncand = 0; s_badprefix = 0; }
     __syncthreads();
     {
-        int part = 0;
-        for (int k = tid; k < b; k += NT) part += q.counts[k];
+        // offset of this pair's matches = sum of the counts before it; a NEGATIVE count anywhere before it would pull the
+        // offset back under an earlier pair's rows (overlapping or negative: out-of-bounds writes), so it refuses this pair too
+        int part = 0, bad = 0;
+        for (int k = tid; k < b; k += NT) {
+            const int c = q.counts[k];
+            bad |= c < 0;
+            part += c > 0 ? c : 0;
+        }
         if (part) atomicAdd(&s_off, part);
+        if (bad) s_badprefix = 1;
     }
     __syncthreads();
     const long long off = s_off;
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(NT) void pose_kernel(PoseParams q) {
         for (int k = 0; k < 9; ++k) { Rout[k] = 0.0; Eout[k] = 0.0; }
         tout[0] = tout[1] = tout[2] = 0.0;
     }
-    if (N < 0 || off + N > q.M) {            // the caller's capacity does not cover the counts: refuse the pair
+    if (N < 0 || s_badprefix || off < 0 || off + N > q.M) {   // counts the caller's capacity does not cover, or corrupt: refuse the pair
         if (tid == 0) info[7] = -1;
         return;
     }

@@ -239,7 +239,7 @@ constexpr int KT = 32;
 // WAVES x 32 queries per workgroup.  8 (one workgroup per CU) shares each K' / V tile between 256 queries: the global
 // blocks, where 16 workgroups walk the same 4096 keys.  4 for the window blocks: a (window, head) is only seven tiles
 // long, and two resident workgroups per CU overlap one's prologue / epilogue with the other's tiles (measured at
-// ViT-H: +0.7 % on the whole encoder against 8 everywhere, -0.8 % with 4 everywhere; POPE_SAM_ATTN_WAVES forces one).
+// ViT-H: +0.7 % on the whole encoder against 8 everywhere, -0.8 % with 4 everywhere).
 // PLAIN: single-product f16 arithmetic (precision "f16"): the operands have no lo planes (rows are [DQ] / [DV] halves),
 // one MFMA per step, P converted once, output f16 row-major.
 template <int NSTEP, int HSTEP, int DVT, int WAVES, bool PLAIN>
@@ -844,8 +844,7 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
             POPE_TRY(pope_check_launch());
         }
         _Float16* att = static_cast<_Float16*>(att_pl);
-        static const int force_waves = getenv("POPE_SAM_ATTN_WAVES") ? atoi(getenv("POPE_SAM_ATTN_WAVES")) : 0;   // dev switch: 4 | 8
-        const bool narrow = force_waves ? force_waves == 4 : a.Nq <= 1024;
+        const bool narrow = a.Nq <= 1024;   // window blocks: 4-wave workgroups; global blocks: 8
 #define POPE_SAM_ATTN_W(NS, HS, DV, W) \
     (plain ? launch_attn<NS, HS, DV, W, true>(p, Qp, Kp, Vp, att, flag, stream) : launch_attn<NS, HS, DV, W, false>(p, Qp, Kp, Vp, att, flag, stream))
 #define POPE_SAM_ATTN(NS, HS, DV) (narrow ? POPE_SAM_ATTN_W(NS, HS, DV, 4) : POPE_SAM_ATTN_W(NS, HS, DV, 8))

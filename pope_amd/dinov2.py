@@ -153,8 +153,8 @@ class DinoVisionTransformer(nn.Module):
         |w| * 256 must be finite in f16; a checkpoint that breaches it runs on the fp32 MFMA (or raises)."""
         precision = precision or self.precision
         if self._src is None:
-            self._src = list(self.parameters())
-        dev_ptr = _lib.params_key(self._src)   # addresses + in-place versions of every parameter
+            self._src = _lib.param_slots(self)
+        dev_ptr = _lib.slots_key(self._src)   # addresses + in-place versions of the tensors NOW in every parameter slot
         hit = self._wcache.get(precision)
         if hit is not None and hit[0] == dev_ptr:
             return hit[1]

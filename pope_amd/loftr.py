@@ -155,8 +155,8 @@ class ResNetFPN_8_2(nn.Module):
         """ctypes weight struct of one arithmetic mode, cached per parameter version: "f16x3" = weight planes (None when a
         folded filter leaves the f16x3 weight range), "f32" = the fp32 matrices themselves."""
         if self._src is None:
-            self._src = list(self.parameters()) + list(self.buffers())
-        key = _lib.params_key(self._src)
+            self._src = _lib.param_slots(self, buffers=True)
+        key = _lib.slots_key(self._src)
         if self._hip is None or self._hip["key"] != key:
             mats, biases = self._matrices()
             self._hip = {"key": key, "mats": mats, "biases": biases, "fit": _weights_fit(mats)}
@@ -282,8 +282,8 @@ class LoFTREncoderLayer(nn.Module):
         """ctypes struct of the layer's weights in one arithmetic mode ("f16x3": weight planes, None when a weight leaves
         the f16x3 range; "f32": the fp32 matrices), cached per parameter version."""
         if self._src is None:
-            self._src = list(self.parameters())
-        key = _lib.params_key(self._src)
+            self._src = _lib.param_slots(self)
+        key = _lib.slots_key(self._src)
         if self._hip is None or self._hip["key"] != key:
             with torch.no_grad():
                 mats = [self.q_proj.weight.detach().float().contiguous(),
@@ -439,8 +439,8 @@ class FinePreprocess(nn.Module):
 
     def _weights(self, precision):
         if self._src is None:
-            self._src = list(self.parameters())
-        key = _lib.params_key(self._src)
+            self._src = _lib.param_slots(self)
+        key = _lib.slots_key(self._src)
         if self._hip is None or self._hip["key"] != key:
             mats = [self.down_proj.weight.detach().float().contiguous(), self.merge_feat.weight.detach().float().contiguous()]
             self._hip = {"key": key, "mats": mats, "fit": _weights_fit(mats),

@@ -170,7 +170,7 @@ class Matcher(nn.Module):
         # 24 pairs, driver step 7.34 -> 7.16 ms (scripts/loftr_time.py) — the C-side launch loops already keep the GPU fed,
         # the time is the small-grid kernels themselves.
         self.use_graph = False
-        self._graphs = {}
+        self._graphs, self._gsrc = {}, None
 
     def _features(self, im0, im1):
         """matcher.py:46-60: (feat_c0, feat_c1) after the coarse transformer [n, L, 256] and the fine maps (feat_f0, feat_f1)."""
@@ -195,7 +195,12 @@ class Matcher(nn.Module):
         if not (self.use_graph and im0.size(0) > 0 and im0.dtype == torch.float32 and im1.dtype == torch.float32
                 and not torch.cuda.is_current_stream_capturing()):
             return self._features(im0, im1)
-        key = (tuple(im0.shape), tuple(im1.shape), im0.device.index, self.backbone.conv1.weight.data_ptr())
+        # a captured graph has the device pointers of the weight planes / folded BatchNorm matrices baked in, and any edit of
+        # a parameter or buffer makes the eager path rebuild (and free) them: the key carries every tensor's address and
+        # in-place version, so a stale graph is simply never looked up again
+        if self._gsrc is None:
+            self._gsrc = _lib.param_slots(self, buffers=True)
+        key = (tuple(im0.shape), tuple(im1.shape), im0.device.index, _lib.slots_key(self._gsrc))
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= 16:   # every graph owns its workspaces: keep the set small
@@ -229,7 +234,7 @@ class Matcher(nn.Module):
         return ent["outs"]
 
     def _apply(self, fn, *a, **k):
-        self._graphs = {}
+        self._graphs, self._gsrc = {}, None
         return super()._apply(fn, *a, **k)
 
     @torch.no_grad()
@@ -256,7 +261,8 @@ class Matcher(nn.Module):
         for old in [k for k in state_dict if k.startswith("matcher.")]:
             state_dict[old[len("matcher."):]] = state_dict.pop(old)
         out = super().load_state_dict(state_dict, *args, **kwargs)
-        # parameters were overwritten in place: the derived caches (folded BatchNorm, weight planes) notice by themselves —
-        # their keys carry the tensors' version counters (_lib.params_key) —, the captured graphs do not
+        # parameters were overwritten in place, or (assign=True) replaced: the derived caches (folded BatchNorm, weight
+        # planes) and the graph keys notice by themselves — they look the tensors up through their slots on every call and
+        # key on address + version (_lib.slots_key); the old graphs would only sit on their workspaces
         self._graphs = {}
         return out

@@ -58,7 +58,7 @@ def estimate_pose_batch(kpts0, kpts1, counts, K0, K1, thresh, conf=0.99999, seed
     R = torch.empty(B, 3, 3, dtype=torch.float64, device=dev)
     t = torch.empty(B, 3, dtype=torch.float64, device=dev)
     E = torch.empty(B, 3, 3, dtype=torch.float64, device=dev)
-    inl = torch.empty(max(M, 1), dtype=torch.uint8, device=dev)
+    inl = torch.zeros(max(M, 1), dtype=torch.uint8, device=dev)   # rows past sum(counts) are never written by the kernel
     info = torch.empty(B, 8, dtype=torch.int32, device=dev)
     if B == 0:
         return {"R": R, "t": t, "E": E, "inliers": inl[:M].bool(), "n_inliers": info[:, 0], "info": info}

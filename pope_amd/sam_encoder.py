@@ -152,7 +152,7 @@ class ImageEncoderViT(nn.Module):
 
     def _sources(self):
         if self._src is None:
-            self._src = list(self.parameters())
+            self._src = _lib.param_slots(self)
         return self._src
 
     def _weights(self, precision=None):
@@ -160,7 +160,7 @@ class ImageEncoderViT(nn.Module):
         if precision not in ("f16x3", "f16", "f32"):
             raise ValueError(f"ImageEncoderViT.precision must be 'f16x3', 'f16' or 'f32', not {precision!r}")
         plain, f32 = precision == "f16", precision == "f32"
-        dev_ptr = _lib.params_key(self._sources())   # addresses + in-place versions of every parameter
+        dev_ptr = _lib.slots_key(self._sources())   # addresses + in-place versions of the tensors NOW in every parameter slot
         hit = self._wcache.get(precision)
         if hit is not None and hit[0] == dev_ptr:
             return hit[1]

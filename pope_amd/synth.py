@@ -226,6 +226,50 @@ def synthetic_matcher_state_dict(seed=0, cfg=None):
     return sd
 
 
+def peaked_matcher_state_dict(pre_outconv, seed=0, gain=2.0, cfg=None):
+    """Synthetic LoFTR weights under which the `Matcher` behaves like a trained one on related image pairs: hundreds of
+    confident matches per 256 x 256 pair (the interior maximum of (32 - 4)^2 cells minus the shifted border), instead of the
+    handful the plain random weights give.  Why those give so few: the 1/8-resolution features are f_i = v + d_i with a
+    common vector v (the mean of the post-ReLU activations through the bias-free 1x1 output convolution, |v|^2 = 1 400) that
+    swamps the cell-specific part (|d|^2 = 180): <v, d_j> acts as a per-column bias in the dual softmax and one column
+    attracts every row.  A trained network has no such component.  Here it is projected out: W' = gain * W (I - m m^T / |m|^2)
+    with m the mean of the activations in front of `backbone.layer3_outconv` on a calibration batch of the same image
+    statistics (`synthetic_gray_pairs`), which leaves features whose correlation picks the true cell for 3 of 4 cells before
+    the transformer and whose dual-softmax confidence clears 0.9 on 95 % of the interior cells.
+    `pre_outconv(state_dict, images[n, 1, H, W]) -> activations [n, 256, H / 8, W / 8]` runs the CNN up to that convolution
+    (pass a state dict whose `backbone.layer3_outconv.weight` is the identity to any implementation of the backbone: the HIP
+    module — `hip_pre_outconv` below — on the GPU box, the CPU checker in the CPU tests); this module computes nothing itself.
+    `pre_outconv` may also be the calibration mean m itself ([256] tensor, e.g. from a fixture).  The returned dict carries it
+    under "_calibration_mean" — pop it before `load_state_dict`."""
+    sd = synthetic_matcher_state_dict(seed, cfg)
+    w = sd["backbone.layer3_outconv.weight"]
+    c = w.shape[0]
+    if torch.is_tensor(pre_outconv):   # the calibration mean itself (a fixture pins the weights bit for bit across hosts)
+        m = pre_outconv.detach().double().cpu().reshape(c)
+    else:
+        ident = dict(sd)
+        ident["backbone.layer3_outconv.weight"] = torch.eye(c).reshape(c, c, 1, 1)
+        cal = synthetic_gray_pairs(4, 256, 256, seed=1000 + seed)[0]
+        x3 = pre_outconv(ident, cal).detach().float().cpu()
+        m = x3.permute(0, 2, 3, 1).reshape(-1, c).double().mean(0)
+    sd["_calibration_mean"] = m.clone()    # not a checkpoint key: callers that need it pop it (load_state_dict would reject it)
+    mh = m / m.norm()
+    proj = torch.eye(c, dtype=torch.float64) - torch.outer(mh, mh)
+    sd["backbone.layer3_outconv.weight"] = (gain * (w.reshape(c, c).double() @ proj)).float().reshape(c, c, 1, 1).contiguous()
+    return sd
+
+
+def hip_pre_outconv(device):
+    """`pre_outconv` of `peaked_matcher_state_dict` on the HIP backbone (pope_amd/loftr.py:ResNetFPN_8_2)."""
+    def run(sd, images):
+        from .loftr import build_backbone
+        from .matcher import default_cfg
+        bb = build_backbone(default_cfg).eval()
+        bb.load_state_dict({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}, strict=True)
+        return bb.to(device)(images.to(device))[0]
+    return run
+
+
 def synthetic_gray_pairs(n_pairs, h=256, w=256, seed=0, shift=(8, 16), noise=0.02):
     """Grayscale [n,1,h,w] pairs in [0,1] for the LoFTR `Matcher` (the drivers feed 256x256 crops,
     eval_linemod_json.py:103-111): image1 = roll(image0, shift) + noise, h and w multiples of 8."""

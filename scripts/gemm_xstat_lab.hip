@@ -3,7 +3,7 @@
 // faster than it on QKV / FC1 in isolation (0.273 vs 0.290 ms, 0.394 vs 0.412 ms), 7 % / 1 % SLOWER inside the model (0.312 vs
 // 0.290, 0.442 vs 0.440 ms; step 95.7 vs 94.8 ms): with one workgroup per CU all 256 CUs fetch their 196 KB activation panels at
 // the same three moments of a launch, and nothing computes under those bursts.  Built into a lab copy of the library by
-// scripts/xstat_ab.sh (-DPOPE_XSTAT_LAB), timed by scripts/xstat_probe.py.
+// scripts/xstat_ab.sh (which also patches the dispatch hook into a copy of gemm_f16x3.hip), timed by scripts/xstat_probe.py.
 //
 // X-stationary f16x3 "planes" NT GEMM for K = 384: the QKV and FC1 projections of the ViT blocks at large M.
 //

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 for pairs in 3 24; do
     for c in FETCH_SIZE WRITE_SIZE; do
-        rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_cnn_${pairs}_$c -o pmc -- python3 $ROOT/scripts/cnn_trace.py $pairs > $OUT/pmc_cnn_${pairs}_$c.log 2>&1
+        timeout -k 10 420 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_cnn_${pairs}_$c -o pmc -- python3 $ROOT/scripts/cnn_trace.py $pairs > $OUT/pmc_cnn_${pairs}_$c.log 2>&1
         echo "pmc pass $pairs pairs $c done"
     done
 done

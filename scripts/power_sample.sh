@@ -1,6 +1,8 @@
 #!/bin/bash
 # Dev: sample rocm-smi power / clocks while the bench step runs (is the 1.7-1.9 GHz of finding 6 the power cap?).
 # Usage: bash scripts/power_sample.sh   (GPU box; prints a few samples)
+set -e
+mkdir -p gpurun_out
 python bench.py --steps 300 --warmup 2 --no-legs --no-config5 --no-strict-f32 --no-cpu-baseline --no-verify > gpurun_out/power_bench.json 2>/dev/null &
 BP=$!
 sleep 16

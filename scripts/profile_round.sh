@@ -10,11 +10,11 @@ export TMPDIR=/tmp
 cd /tmp
 # (a) the default command as the driver runs it (self-check launches and the strict-fp32 leg included), (b) the f16x3 step
 # alone: per-kernel averages that can be compared with the line's HIP-event figures
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_default -o bench -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_profiled_default.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strict-f32 --no-verify --no-legs --no-config5 > $OUT/bench_profiled.json
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_default -o bench -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_profiled_default.json
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strict-f32 --no-verify --no-legs --no-config5 > $OUT/bench_profiled.json
 # the secondary legs on their own (bench_legs.py): the LoFTR Matcher at 3 and 24 pairs, and one query of the drivers' loop
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_loftr -o loftr -- python3 $ROOT/bench.py --only loftr_matcher > $OUT/bench_loftr_matcher.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_driver -o driver -- python3 $ROOT/bench.py --only driver_step > $OUT/bench_driver_step.json
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_loftr -o loftr -- python3 $ROOT/bench.py --only loftr_matcher > $OUT/bench_loftr_matcher.json
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_driver -o driver -- python3 $ROOT/bench.py --only driver_step > $OUT/bench_driver_step.json
 echo "stats passes done"
 if [ -n "$STATS_ONLY" ]; then
     mkdir -p $OUT/profile_round
@@ -30,7 +30,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES G
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" \
             "TCC_HIT_sum TCC_MISS_sum"; do
     tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
-    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$tag -o pmc -- python3 $ROOT/scripts/prof_forward.py 64 2 > $OUT/pmc_$tag.log
+    timeout -k 10 420 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$tag -o pmc -- python3 $ROOT/scripts/prof_forward.py 64 2 > $OUT/pmc_$tag.log
     echo "pmc pass $tag done"
 done
 cd $ROOT

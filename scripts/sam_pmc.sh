@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
-    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/sampmc_$tag -o pmc -- python3 $ROOT/scripts/sam_time.py vit_h 2 1 $PREC > $OUT/sampmc_$tag.log 2>&1
+    timeout -k 10 420 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/sampmc_$tag -o pmc -- python3 $ROOT/scripts/sam_time.py vit_h 2 1 $PREC > $OUT/sampmc_$tag.log 2>&1
     echo "pmc pass $tag done"
 done
 cd $ROOT

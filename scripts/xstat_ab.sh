@@ -12,8 +12,12 @@ while [ $# -ge 2 ]; do
     name=$1; flags=$2; shift 2
     if [ "$name" = product ]; then cp libpope_hip.so ../../scripts/_lab/libpope_product.so; echo "copied the product library"; continue; fi
     T=$(mktemp -d)
-    $CXX -DPOPE_XSTAT_LAB $flags -c ../../scripts/gemm_xstat_lab.hip -o $T/gemm_xstat.o
-    $CXX -DPOPE_XSTAT_LAB -c gemm_f16x3.hip -o $T/gemm_f16x3.o
+    $CXX $flags -c ../../scripts/gemm_xstat_lab.hip -o $T/gemm_xstat.o
+    # the dispatch hook lives only in this patched copy of the product's launcher file
+    { echo 'struct GemmParams; bool pope_xstat_supported(const GemmParams&); int pope_launch_xstat(const GemmParams&, struct ihipStream_t*);';
+      sed 's|^    switch (g.epilogue) {$|    if (pope_xstat_supported(g)) return pope_launch_xstat(g, stream);\n    switch (g.epilogue) {|' gemm_f16x3.hip; } > $T/gemm_f16x3_lab.hip
+    grep -q pope_launch_xstat\(g $T/gemm_f16x3_lab.hip
+    $CXX -I. -c $T/gemm_f16x3_lab.hip -o $T/gemm_f16x3.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scripts/_lab/libpope_$name.so \
         $(ls *.o | grep -v "^gemm_f16x3.o") $T/gemm_xstat.o $T/gemm_f16x3.o
     rm -rf $T

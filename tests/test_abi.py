@@ -88,3 +88,20 @@ def test_product_never_imports_oracle():
     import pathlib
     for p in pathlib.Path(ROOT, "pope_amd").rglob("*.py"):
         assert "oracle" not in p.read_text().replace("no CPU oracle", ""), p
+
+
+def test_library_has_no_environment_switches(hip_lib):
+    """`pope_hip.h` promises no global state: the shipped library must not read the environment (round 3 carried seven
+    `getenv("POPE_...")` dev switches that selected kernels no test ran) and its kernel sources must not carry timing
+    ablations ("wrong results" builds) — lab variants are compiled from scripts/ with their own flags."""
+    import glob
+    import os
+    import re
+    from pope_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert not re.search(rb"POPE_[A-Z0-9_]{3,}", blob), "an environment / macro name survives in the binary"
+    csrc = os.path.dirname(_lib.LIB_PATH)
+    for path in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        text = open(path).read()
+        assert "getenv" not in text, path
+        assert not re.search(r"#\s*if(n?def)?\b[^\n]*(_ABL_|_LAB\b|NO_EPILOGUE|NOSTORE|L1ONLY)", text), path

@@ -26,6 +26,21 @@ def models(dev, sd0):
     return vit, matcher.to(dev)
 
 
+@pytest.fixture(scope="module")
+def peaked_models(dev, sd0, golden_dir):
+    """DINOv2 + the LoFTR Matcher under the `peaked` synthetic weights (synth.peaked_matcher_state_dict, pinned by the
+    calibration mean of the 512 x 512 reference fixture): hundreds of matches per related pair, like a trained checkpoint."""
+    from pope_amd import synth
+    from pope_amd.dinov2_utils import load_dinov2_model
+    from pope_amd.matcher import Matcher, default_cfg
+    fx = np.load(os.path.join(golden_dir, "loftr_512_peaked.npz"))
+    sd = synth.peaked_matcher_state_dict(torch.from_numpy(fx["outconv_mean"]), seed=0)
+    sd.pop("_calibration_mean")
+    matcher = Matcher(default_cfg).eval()
+    matcher.load_state_dict(sd, strict=True)
+    return load_dinov2_model(state_dict=sd0).to(dev), matcher.to(dev)
+
+
 def test_driver_step_matches_reference_loop(dev, models, golden_dir):
     from pope_amd import synth
     from pope_amd.driver import locate_and_match
@@ -64,14 +79,16 @@ def test_driver_step_with_fewer_than_three_candidates(dev, models):
     assert out["best_slot"] == 0 and out["best_proposal"] == 0 and len(out["mconf"][0]) > 0
 
 
-def test_whole_query_from_frame_and_boxes_to_pose(dev, models):
+def test_whole_query_from_frame_and_boxes_to_pose(dev, peaked_models):
     """locate_match_pose_u8: frame + proposal boxes -> crops + K (one launch) -> preprocessing -> vote -> LoFTR -> pose,
     against the same chain assembled from the oracles (oracle/crop_ref.py crops and intrinsics, oracle/pose_ref.py on the
-    published matches)."""
+    published matches).  Round 3 ran this on the plain random LoFTR weights, got 6 matches in the best slot and lowered its
+    bound to the RANSAC minimum; under the `peaked` weights the planted proposals publish hundreds of matches (the load of the
+    reference's trained checkpoint) and the pose stage sees a real problem."""
     from oracle import crop_ref, pose_ref
     from pope_amd import synth
     from pope_amd.driver import locate_and_match_u8, locate_match_pose_u8
-    vit, matcher = models
+    vit, matcher = peaked_models
     ref, frame, boxes, K0, K1 = synth.synthetic_frame_case()
     out = locate_match_pose_u8(vit, matcher, ref, frame, boxes, K0, K1)
     crops_ref = np.stack([crop_ref.crop_proposal(frame, b, K1)[0] for b in boxes])
@@ -82,13 +99,13 @@ def test_whole_query_from_frame_and_boxes_to_pose(dev, models):
     assert torch.equal(out["scores"], want["scores"]) and list(out["slot_index"]) == list(want["slot_index"])
     assert out["best_proposal"] in (1, 4) and set(out["slot_index"]) >= {1, 4}     # the planted proposals win the vote
     s = out["best_slot"]
-    assert np.array_equal(out["mkpts0"][s], want["mkpts0"][s]) and len(out["mconf"][s]) >= 5
+    assert np.array_equal(out["mkpts0"][s], want["mkpts0"][s]) and len(out["mconf"][s]) >= 300
     assert np.array_equal(out["pre_K"], out["K_crops"][out["best_proposal"]])
     ret = pose_ref.estimate_pose(out["mkpts0"][s], out["mkpts1"][s], K0, out["pre_K"], 0.5, 0.99)
     assert (ret is None) == (out["pose"] is None)
     if ret is not None:
         R, t, inl = out["pose"]
         print(f"best proposal {out['best_proposal']}: {len(out['mconf'][s])} matches, {int(inl.sum())} pose inliers")
-        assert np.array_equal(inl, ret[2]) and inl.sum() >= 5
+        assert np.array_equal(inl, ret[2]) and inl.sum() >= 30
         np.testing.assert_allclose(R, ret[0], atol=1e-7)
         np.testing.assert_allclose(t, ret[1], atol=1e-7)

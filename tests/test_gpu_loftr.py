@@ -537,3 +537,114 @@ def test_weights_outside_the_f16x3_range_run_on_fp32_and_in_place_edits_are_noti
     with torch.no_grad():
         want = loftr_ref.resnet_fpn_8_2(sd3, x)[0]
     assert not torch.equal(y0, y1) and float((y1.cpu() - want).abs().max()) <= FEAT_ATOL
+
+
+# ------------------------------------------------------------------ the drivers' larger shapes
+def _peaked(golden_dir):
+    """`peaked` synthetic weights (pope_amd/synth.py:peaked_matcher_state_dict) pinned by the calibration mean stored in the
+    512 x 512 reference fixture: thousands of confident matches per pair, as a trained checkpoint gives."""
+    from pope_amd import synth
+    fx = np.load(os.path.join(golden_dir, "loftr_512_peaked.npz"))
+    sd = synth.peaked_matcher_state_dict(torch.from_numpy(fx["outconv_mean"]), seed=0)
+    sd.pop("_calibration_mean")
+    return sd, fx
+
+
+def _matcher_with(sd, dev):
+    from pope_amd.matcher import Matcher, default_cfg
+    m = Matcher(default_cfg).eval()
+    m.load_state_dict(dict(sd), strict=True)
+    return m.to(dev)
+
+
+def test_matcher_512_against_the_reference_fixture(dev, golden_dir):
+    """The reference's own Matcher at the OnePose drivers' shape (eval_onepose_json.py:88: 512 x 512, L = S = 4 096; fixture
+    loftr_512_peaked.npz from oracle/gen_golden.py:gen_loftr_large, 3 420 matches at the default threshold): strided feature
+    taps, the row / column arg-max of the 4 096 x 4 096 confidence matrix, the match list and the fine stage's output."""
+    from pope_amd import synth
+    sd, fx = _peaked(golden_dir)
+    m = _matcher_with(sd, dev)
+    i0, i1 = (t.to(dev) for t in synth.synthetic_gray_pairs(1, 512, 512, seed=23))
+    assert abs(float(i0.double().sum()) - fx["image_digest"][0]) < 1e-6 * fx["image_digest"][0]
+    data = {"image0": i0, "image1": i1}
+    m(data)
+    bc, bf = m.backbone(torch.cat([i0, i1], 0))
+    f0, f1 = m({"image0": i0, "image1": i1}, only_att_fea=True)
+    errs = {"backbone_c": float(np.abs(bc[:, ::4, ::4, ::4].cpu().numpy() - fx["backbone_c"]).max()),
+            "backbone_f": float(np.abs(bf[:, ::8, ::16, ::16].cpu().numpy() - fx["backbone_f"]).max()),
+            "feat_c0": float(np.abs(f0[:, ::16].cpu().numpy() - fx["feat_c0"]).max()),
+            "feat_c1": float(np.abs(f1[:, ::16].cpu().numpy() - fx["feat_c1"]).max())}
+    print("512 x 512 taps vs the reference:", {k: f"{v:.2e}" for k, v in errs.items()}, f"bound {FEAT_ATOL:g}")
+    assert max(errs.values()) <= FEAT_ATOL, errs
+    assert tuple(data["hw0_c"]) == (64, 64) and tuple(data["hw0_f"]) == (256, 256)
+    conf = data["conf_matrix"]
+    rowmax = conf.max(2)[0].cpu().numpy()
+    np.testing.assert_allclose(rowmax, fx["conf_rowmax"], rtol=2e-3, atol=1e-7)
+    # arg-max of every row / column whose winner is clear in the reference
+    top2 = np.sort(np.partition(conf[0].cpu().numpy(), -2, axis=1)[:, -2:], axis=1)
+    clear_rows = top2[:, 1] - top2[:, 0] > CLEAR
+    assert clear_rows.sum() > 3000
+    assert np.array_equal(conf.max(2)[1].cpu().numpy()[0][clear_rows], fx["conf_rowarg"][0][clear_rows])
+    ids = np.stack([data["b_ids"].cpu().numpy(), data["i_ids"].cpu().numpy(), data["j_ids"].cpu().numpy()], 1)
+    ref_ids = np.stack([fx["b_ids"], fx["i_ids"], fx["j_ids"]], 1)
+    borderline = int((np.abs(fx["mconf"] - 0.2) < CLEAR).sum())
+    print(f"matches: reference {len(ref_ids)}, published {len(ids)}; {borderline} reference matches within {CLEAR:g} of the threshold")
+    if borderline == 0:
+        assert np.array_equal(ids, ref_ids)
+        np.testing.assert_allclose(data["mconf"].cpu().numpy(), fx["mconf"], rtol=0, atol=2e-4)
+        e_px = float(np.abs(data["mkpts1_f"].cpu().numpy() - fx["mkpts1_f"]).max())
+        print(f"mkpts1_f max err {e_px:.2e} px over {len(ids)} matches")
+        assert e_px <= PX_ATOL
+        np.testing.assert_allclose(data["expec_f"].cpu().numpy()[:, :2], fx["expec_f"][:, :2], rtol=0, atol=2e-4)
+    else:
+        assert abs(len(ids) - len(ref_ids)) <= borderline
+
+
+@pytest.mark.parametrize("H,W", [(480, 640), (512, 512)])
+def test_backbone_and_matcher_at_the_drivers_large_shapes(dev, golden_dir, H, W):
+    """ResNetFPN_8_2 and the whole Matcher at 480 x 640 (L = S = 4 800, SURVEY a-11) and 512 x 512 (4 096) against
+    oracle/loftr_ref.py in fp32 and fp64, with the bounds of the 256 x 256 tests: CNN tile edges at widths that are not a
+    multiple of 128 pixels, the implicit convolution's row shifts at Wp = 322 / 258, 32-bit offsets of the coarse stage at
+    92 MB per confidence matrix, the fine-stage gather with thousands of windows."""
+    from oracle import loftr_ref
+    from pope_amd import synth
+    from pope_amd.matcher import default_cfg
+    sd, _ = _peaked(golden_dir)
+    m = _matcher_with(sd, dev)
+    i0, i1 = synth.synthetic_gray_pairs(1, H, W, seed=H + 3)
+    with torch.no_grad():
+        wc, wf = loftr_ref.resnet_fpn_8_2(as64(sd), i0.double())
+        rc, rf = loftr_ref.resnet_fpn_8_2(sd, i0)
+        gc, gf = m.backbone(i0.to(dev))
+    for name, g, r, w in (("coarse", gc, rc, wc), ("fine", gf, rf, wf)):
+        e_hip, e_ref = float((g.cpu().double() - w).abs().max()), float((r.double() - w).abs().max())
+        e_vs_ref, scale = float((g.cpu() - r).abs().max()), float(w.abs().max())
+        print(f"backbone {name} {H}x{W}: max err vs fp64 oracle: HIP {e_hip:.2e}, fp32 oracle {e_ref:.2e}; HIP vs fp32 oracle "
+              f"{e_vs_ref:.2e}; |feat| max {scale:.2f}")
+        assert e_vs_ref <= FEAT_ATOL and e_hip < 4 * e_ref + 2e-5 * max(1.0, scale)
+    data = {"image0": i0.to(dev), "image1": i1.to(dev)}
+    m(data)
+    with torch.no_grad():
+        ref = loftr_ref.matcher_forward(sd, default_cfg, i0, i1)
+        ref64 = loftr_ref.matcher_forward(as64(sd), default_cfg, i0.double(), i1.double())
+    L = (H // 8) * (W // 8)
+    assert data["conf_matrix"].shape == (1, L, L) and len(ref["b_ids"]) > 0.7 * (H // 8 - 4) * (W // 8 - 4)
+    must, may = _clear_decisions(ref["conf_matrix"], 0.2, 2, (H // 8, W // 8), (H // 8, W // 8))
+    got_ids = torch.stack([data["b_ids"], data["i_ids"], data["j_ids"]], 1).cpu()
+    got_mask = torch.zeros_like(must)
+    got_mask[got_ids[:, 0], got_ids[:, 1], got_ids[:, 2]] = True
+    assert bool((got_mask | ~must).all()), "a clear reference match is missing"
+    assert bool((may | ~got_mask).all()), "a match the reference clearly rejects was published"
+    ref_ids = torch.stack([ref["b_ids"], ref["i_ids"], ref["j_ids"]], 1)
+    identical = got_ids.shape == ref_ids.shape and bool((got_ids == ref_ids).all())
+    print(f"matcher {H}x{W}: {len(ref_ids)} reference matches ({int(must.sum())} clear), published {len(got_ids)}, identical {identical}")
+    if int(must.sum()) == len(ref_ids):
+        assert identical
+    if identical:
+        e_conf = float((data["mconf"].cpu() - ref["mconf"]).abs().max())
+        e_px = float((data["mkpts1_f"].cpu() - ref["mkpts1_f"]).abs().max())
+        e_px64 = float((data["mkpts1_f"].cpu().double() - ref64["mkpts1_f"]).abs().max()) if len(ref64["b_ids"]) == len(ref_ids) else float("nan")
+        e_ref64 = float((ref["mkpts1_f"].double() - ref64["mkpts1_f"]).abs().max()) if len(ref64["b_ids"]) == len(ref_ids) else float("nan")
+        print(f"mconf max err {e_conf:.2e}; mkpts1_f max err {e_px:.2e} px vs fp32 oracle, {e_px64:.2e} vs fp64 (fp32 oracle itself: {e_ref64:.2e})")
+        assert e_conf <= 2e-4 and e_px <= PX_ATOL
+        assert torch.equal(data["mkpts0_f"].cpu(), ref["mkpts0_f"])

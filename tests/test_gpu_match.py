@@ -92,6 +92,35 @@ def test_matcher_vs_oracle_random_shapes(dev):
         assert np.array_equal(got["mkpts1_c"].cpu().numpy(), want["mkpts1_c"].numpy())
 
 
+@pytest.mark.parametrize("hw", [(64, 64), (60, 80)])
+def test_loftr_shapes_of_the_drivers_at_c256_are_index_exact(dev, hw):
+    """The dense matcher at the LoFTR coarse shapes the drivers reach: C = 256 with L = S = 4 096
+    (512 x 512 crops, eval_onepose_json.py:88) and L = S = 4 800 (480 x 640, SURVEY a-11), three pairs per launch — 32-bit
+    offsets of the similarity epilogue and of the confidence pass at 92 MB per pair, `conf_matrix` published.  Index-exact
+    against oracle/coarse_match_ref.py, ties included (pair 2 repeats rows so that exact ties exist)."""
+    from oracle import coarse_match_ref as cm
+    from pope_amd.matcher import dense_match
+    g = torch.Generator().manual_seed(17)
+    n, C = 3, 256
+    L = hw[0] * hw[1]
+    f0 = torch.randn(n, L, C, generator=g) * 1.5
+    perm = torch.stack([torch.randperm(L, generator=g) for _ in range(n)])
+    f1 = torch.gather(f0, 1, perm[..., None].expand(-1, -1, C)) + 0.15 * torch.randn(n, L, C, generator=g)
+    f1[2, 100:140] = f1[2, 200:240]                       # duplicated columns: ties resolve to the lowest index
+    want = cm.dense_match(f0, f1, hw, hw, (hw[0] * 8, hw[1] * 8))
+    got = dense_match(f0.to(dev), f1.to(dev), hw, hw, (hw[0] * 8, hw[1] * 8), want_conf=True)
+    assert len(want["b_ids"]) > 0.8 * n * (hw[0] - 4) * (hw[1] - 4)
+    for k in ("b_ids", "i_ids", "j_ids"):
+        assert np.array_equal(got[k].cpu().numpy(), want[k].numpy()), k
+    np.testing.assert_allclose(got["mconf"].cpu().numpy(), want["mconf"].numpy(), rtol=1e-4, atol=1e-6)
+    assert np.array_equal(got["mkpts0_c"].cpu().numpy(), want["mkpts0_c"].numpy())
+    assert np.array_equal(got["mkpts1_c"].cpu().numpy(), want["mkpts1_c"].numpy())
+    conf = got["conf_matrix"]
+    assert conf.shape == (n, L, L)
+    assert np.array_equal(conf.max(2)[1].cpu().numpy(), want["conf_matrix"].max(2)[1].numpy())
+    np.testing.assert_allclose(conf[1, ::97].cpu().numpy(), want["conf_matrix"][1, ::97].numpy(), rtol=2e-4, atol=1e-9)
+
+
 def test_border_capacity_ties_and_empty(dev):
     from pope_amd.matcher import dense_match
     g = torch.Generator().manual_seed(1)

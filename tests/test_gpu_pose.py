@@ -101,17 +101,60 @@ def test_planted_pose_is_recovered(dev, n, outlier):
 
 
 def test_noisy_matches_at_the_drivers_threshold(dev):
-    """0.3 px noise, 0.5 px threshold, conf 0.99 (eval_linemod_json.py:160): a usable pose, most planted inliers kept."""
+    """0.3 px noise, 0.5 px threshold, conf 0.99 (eval_linemod_json.py:160).  Round 3 widened this test's bound from
+    (2 deg, 10 deg) to (5 deg, 20 deg) after scene 1 came out at 2.29 deg / 8.38 deg.  Scene-dependent errors of a few
+    degrees are the ALGORITHM's: a five-point RANSAC returns the best MINIMAL-sample model, unrefined (as cv2.findEssentialMat
+    does, metrics.py:80-94), so its accuracy is that of five noisy matches.  What the kernel owes is the algorithm's answer:
+    on every scene the GPU must return the checker's pose (oracle/pose_ref.py on the same samples: same winner, same inlier
+    mask, R / t to 1e-6), the checker's own error against the planted pose is printed beside it, and the (2 deg, 10 deg) bound
+    is held on the MEDIAN over the eight scenes with a loose sanity bound on each."""
     from pope_amd import pose, synth
     scenes = [synth.synthetic_pose_scene(300, 40 + seed, outlier=0.3, noise=0.3) for seed in range(8)]
     k0, k1, counts, K0, K1 = pack(scenes, dev)
     out = pose.estimate_pose_batch(k0, k1, counts, K0, K1, 0.5, 0.99)
-    R, t, inl = out["R"].cpu().numpy(), out["t"].cpu().numpy(), out["inliers"].cpu().numpy()
+    R, t, inl, info = (out[k].cpu().numpy() for k in ("R", "t", "inliers", "info"))
+    errs = []
     for b, s in enumerate(scenes):
-        t_err, R_err = pose_error(R[b], t[b], s[4], s[5])
+        ret, oi = P.estimate_pose(s[0], s[1], s[2], s[3], 0.5, 0.99, return_info=True)
         got = inl[300 * b:300 * (b + 1)]
-        assert R_err < 5.0 and t_err < 20.0, (b, R_err, t_err)   # minimal-sample RANSAC without refinement, as the reference
+        assert ret is not None and (info[b, 4], info[b, 5]) == oi["best"] and info[b, 1] == oi["inliers"], b
+        assert np.array_equal(got, ret[2]), b
+        # same root of the same polynomial found by Sturm + Newton here and by companion-matrix eigenvalues in the checker:
+        # the pose inherits eps x the root's condition number, which noisy minimal samples push to ~1e10 (measured 1.2e-6)
+        np.testing.assert_allclose(R[b], ret[0], atol=1e-5)
+        np.testing.assert_allclose(t[b], ret[1], atol=1e-5)
+        t_err, R_err = pose_error(R[b], t[b], s[4], s[5])
+        t_ora, R_ora = pose_error(ret[0], ret[1], s[4], s[5])
+        print(f"scene {b}: gpu R {R_err:.3f} deg t {t_err:.3f} deg | checker R {R_ora:.3f} deg t {t_ora:.3f} deg | "
+              f"{info[b, 1]} RANSAC inliers of {int(s[6].sum())} planted, {info[b, 2]} hypotheses")
+        assert abs(R_err - R_ora) < 1e-4 and abs(t_err - t_ora) < 1e-3
+        errs.append((R_err, t_err))
+        assert R_err < 6.0 and t_err < 25.0, (b, R_err, t_err)        # sanity: a usable pose on every scene
         assert (got & s[6]).sum() >= 0.6 * s[6].sum() and (got & ~s[6]).sum() <= 3
+    R_med, t_med = np.median([e[0] for e in errs]), np.median([e[1] for e in errs])
+    print(f"median over the scenes: R {R_med:.3f} deg, t {t_med:.3f} deg")
+    assert R_med < 2.0 and t_med < 10.0
+
+
+def test_corrupt_counts_refuse_the_pairs_behind_them(dev):
+    """a negative count must not pull the offsets of the pairs behind it back under earlier rows; rows of
+    `inliers` past sum(counts) read as zero (the kernel never writes them)."""
+    from pope_amd import pose, synth
+    scenes = [synth.synthetic_pose_scene(40, 70 + k, outlier=0.2, noise=0.1) for k in range(4)]
+    k0, k1, counts, K0, K1 = pack(scenes, dev)
+    good = pose.estimate_pose_batch(k0, k1, counts, K0, K1, 0.5, 0.99)
+    bad_counts = counts.clone()
+    bad_counts[1] = -40
+    out = pose.estimate_pose_batch(k0, k1, bad_counts, K0, K1, 0.5, 0.99)
+    info = out["info"].cpu().numpy()
+    assert info[0, 7] == 0 and torch.equal(out["R"][0], good["R"][0])       # the pair in front is untouched
+    assert list(info[1:, 7]) == [-1, -1, -1] and list(info[1:, 0]) == [0, 0, 0]
+    assert int(out["inliers"][40:].sum()) == 0
+    # capacity larger than the matches: the tail of the mask is zeros, the head is the unpadded call's mask
+    pad = torch.zeros(25, 2, device=dev)
+    out = pose.estimate_pose_batch(torch.cat([k0, pad]), torch.cat([k1, pad]), counts, K0, K1, 0.5, 0.99)
+    assert out["inliers"].numel() == 185 and int(out["inliers"][160:].sum()) == 0
+    assert torch.equal(out["inliers"][:160], good["inliers"]) and torch.equal(out["R"], good["R"])
 
 
 def test_deterministic_and_batch_invariant(dev):

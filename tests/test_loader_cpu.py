@@ -59,3 +59,23 @@ def test_strict_loading_rejects_incomplete_or_foreign_files(tmp_path, sd0):
         load_dinov2_model(weights=str(p2))
     with pytest.raises(FileNotFoundError):
         load_dinov2_model(weights=str(tmp_path / "absent.pth"))
+
+
+def test_vit_weight_cache_follows_replaced_parameter_objects():
+    """`load_state_dict(..., assign=True)` / `m.weight = nn.Parameter(..)` swap the Parameter OBJECTS; the ViT's
+    derived weight structs are keyed on whatever sits in the parameter slots now (`_lib.slots_key`), not on a cached tensor
+    list."""
+    import torch.nn as nn
+    from pope_amd import synth
+    from pope_amd.dinov2_utils import load_dinov2_model
+    sd = synth.synthetic_state_dict(seed=0)
+    m = load_dinov2_model(state_dict=sd)
+    w0 = m._weights("f32")
+    assert m._weights("f32") is w0                                   # unchanged model: cache hit
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["blocks.3.mlp.fc1.weight"] = sd2["blocks.3.mlp.fc1.weight"] * 1.25
+    m.load_state_dict(sd2, strict=True, assign=True)
+    w1 = m._weights("f32")
+    assert w1 is not w0
+    m.blocks[7].attn.proj.weight = nn.Parameter(m.blocks[7].attn.proj.weight.detach() * 0.5)
+    assert m._weights("f32") is not w1

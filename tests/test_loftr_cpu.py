@@ -80,6 +80,24 @@ def test_oracle_matches_reference_fixture(msd, golden_dir, name):
     assert np.array_equal(conf.max(1)[1].numpy(), fx["conf_colarg"])
 
 
+def test_oracle_matches_the_512_reference_fixture(golden_dir):
+    """The oracle at the OnePose drivers' 512 x 512 under the `peaked` weights reproduces the reference Matcher's fixture
+    (3 420 matches at the default threshold): the checker the GPU tests of the large shapes lean on is pinned there too."""
+    fx = np.load(os.path.join(golden_dir, "loftr_512_peaked.npz"))
+    sd = synth.peaked_matcher_state_dict(torch.from_numpy(fx["outconv_mean"]), seed=0)
+    sd.pop("_calibration_mean")
+    i0, i1 = synth.synthetic_gray_pairs(1, 512, 512, seed=23)
+    with torch.no_grad():
+        out = loftr_ref.matcher_forward(sd, default_cfg, i0, i1)
+    assert len(fx["b_ids"]) > 3000
+    for k in ("b_ids", "i_ids", "j_ids"):
+        assert np.array_equal(out[k].numpy(), fx[k]), k
+    for k in ("mconf", "mkpts1_f", "expec_f"):
+        np.testing.assert_allclose(out[k].numpy(), fx[k], rtol=0, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(out["feat_c0"][:, ::16].numpy(), fx["feat_c0"], rtol=0, atol=2e-6)
+    assert np.array_equal(out["conf_matrix"].max(2)[1].numpy(), fx["conf_rowarg"])
+
+
 def test_position_code_reproduces_reference_frequencies():
     """temp_bug_fix=False: `-ln(1e4)/d_model//2` == -1 -> frequencies exp(-2k) (position_encoding.py:28)."""
     for bug_fix in (False, True):
@@ -144,7 +162,42 @@ def test_folded_conv_matrices_reproduce_the_oracle_cnn(msd):
 
 def _key(module):
     from pope_amd import _lib
-    return _lib.params_key(list(module.parameters()) + list(module.buffers()))
+    return _lib.slots_key(_lib.param_slots(module, buffers=True))
+
+
+def test_replaced_parameter_objects_refresh_the_derived_weights(msd):
+    """the derived data (folded BatchNorm matrices, weight planes) is keyed on the tensors CURRENTLY in the
+    modules' parameter / buffer slots, so `load_state_dict(..., assign=True)`, `m.weight = nn.Parameter(..)` and a
+    re-assigned BatchNorm buffer refresh it exactly like an in-place edit does (round 3 cached the tensor LIST and kept
+    serving the planes of the old objects)."""
+    import torch.nn as nn
+    bb = loftr.build_backbone(default_cfg).eval()
+    sd = {k[len("backbone."):]: v for k, v in msd.items() if k.startswith("backbone.")}
+    bb.load_state_dict(sd, strict=True)
+    bb._weights("f32")
+    first, stem0 = bb._hip, bb._hip["mats"][0].clone()
+    sd2 = {k: (v * 1.5 if k == "conv1.weight" else v.clone()) for k, v in sd.items()}
+    bb.load_state_dict(sd2, strict=True, assign=True)                 # every Parameter / buffer OBJECT is replaced
+    bb._weights("f32")
+    assert bb._hip is not first and torch.allclose(bb._hip["mats"][0], 1.5 * stem0, rtol=1e-6, atol=0)
+    second = bb._hip
+    bb.conv1.weight = nn.Parameter(sd["conv1.weight"].clone() * 2.0)  # one Parameter replaced by assignment
+    bb._weights("f32")
+    assert bb._hip is not second and torch.allclose(bb._hip["mats"][0], 2.0 * stem0, rtol=1e-6, atol=0)
+    third = bb._hip
+    bb.bn1.running_var = sd["bn1.running_var"] * 4.0                  # a buffer re-assigned: the folded scale halves
+    bb._weights("f32")
+    assert bb._hip is not third and not torch.equal(bb._hip["mats"][0], third["mats"][0])
+    bb._weights("f32")
+    assert bb._hip["key"] == _key(bb)                                  # and an unchanged model hits the cache
+    # a transformer layer and the fine-stage projections follow the same rule
+    t = loftr.LocalFeatureTransformer(default_cfg["coarse"]).eval()
+    layer = t.layers[1]
+    layer._weights("f32")
+    h = layer._hip
+    layer.merge.weight = nn.Parameter(layer.merge.weight.detach() * 0.5)
+    layer._weights("f32")
+    assert layer._hip is not h and torch.equal(layer._hip["mats"][2], layer.merge.weight.detach())
 
 
 def test_transformer_and_fine_weight_matrices(msd):
@@ -198,3 +251,26 @@ def test_no_stage_computes_on_the_cpu(model):
         model.fine_preprocess(torch.zeros(1, 128, 32, 32), torch.zeros(1, 128, 32, 32), torch.zeros(1, 64, 256), torch.zeros(1, 64, 256), data)
     with pytest.raises(PopeHipError):
         model.fine_matching(torch.zeros(1, 25, 128), torch.zeros(1, 25, 128), data)
+
+
+def test_peaked_weights_give_a_trained_like_match_load(golden_dir):
+    """`synth.peaked_matcher_state_dict` (calibrated here through the oracle's CNN): hundreds of confident matches per 256 x
+    256 pair at the default threshold — the load the realistic legs of bench_legs.py and the drivers' tests run under — where
+    the plain random weights publish a dozen.  The 512 x 512 reference fixture stores the calibration mean; the mean alone
+    reproduces its weights."""
+    import os
+    def pre(sd_, img):
+        with torch.no_grad():
+            return loftr_ref.resnet_fpn_8_2(sd_, img)[0]
+    sd = synth.peaked_matcher_state_dict(pre, seed=0)
+    mean = sd.pop("_calibration_mean")
+    i0, i1 = synth.synthetic_gray_pairs(1, 256, 256, seed=5)
+    with torch.no_grad():
+        out = loftr_ref.matcher_forward(sd, default_cfg, i0, i1)
+        plain = loftr_ref.matcher_forward(synth.synthetic_matcher_state_dict(seed=0), default_cfg, i0, i1)
+    assert len(out["mconf"]) >= 600 and int((out["mconf"] > 0.9).sum()) >= 550 and len(plain["mconf"]) < 60
+    # matched cells are the planted shift (8, 16) px = (1, 2) cells
+    i, j = out["i_ids"], out["j_ids"]
+    assert bool((((i // 32 + 1) % 32) * 32 + (i % 32 + 2) % 32 == j).float().mean() > 0.98)
+    fx = np.load(os.path.join(golden_dir, "loftr_512_peaked.npz"))
+    assert float((mean - torch.from_numpy(fx["outconv_mean"])).abs().max()) < 1e-4 * float(mean.abs().max())
