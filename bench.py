@@ -442,7 +442,20 @@ def main():
                 pipe.want_conf = False
                 torch.cuda.empty_cache()
             try:
-                result["attention_ramp"] = bench_legs.attention_ramp_leg(device, chunk=args.chunk)
+                ramp = bench_legs.attention_ramp_leg(device, chunk=args.chunk)
+                result["attention_ramp"] = ramp
+                # the headline if the model's attention scores behaved like the steepest ramp instead of the synthetic weights'
+                # diffuse rows: every attention launch of the step charged the leg's measured difference to its ramp-0 time
+                # (same run, same box).  Since round 4 the kernel advances its softmax reference BEFORE a tile's
+                # exponentials (nothing is recomputed) and the difference is a few per cent either way.
+                r = ramp["ramps_log2_units_per_tile"]
+                worst = max(r, key=lambda k: r[k]["ms"])
+                extra_ms = (r[worst]["ms"] - r["0.0"]["ms"]) * n_chunks * DEPTH
+                result["value_at_ramp"] = {"ramp": float(worst), "value": round(pairs_per_step_total / ((1e3 * elapsed / args.steps + max(extra_ms, 0.0)) * 1e-3), 2),
+                                           "unit": "image-pairs/s", "attention_ms": {k: v["ms"] for k, v in r.items()},
+                                           "how": "derived: ms_per_step + (attention launches per step) x (ms at the slowest ramp - ms at ramp 0) of "
+                                                  "the attention_ramp leg of this run; advance_rate at that ramp: "
+                                                  f"{r[worst]['advance_rate']}"}
             except Exception as e:  # noqa: BLE001
                 result["attention_ramp"] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()

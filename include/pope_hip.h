@@ -121,9 +121,9 @@ int pope_attention_prec_f32(const float* qkv, float* out, int B, int N, int head
 int pope_attention_planes_f32(const void* qkv_planes, void* out_planes, int B, int N, int heads, void* stream);
 
 /* Measurement only: pope_attention_planes_f32 through a diagnostic instantiation of the same kernel that counts the
- * (wave, 64-key tile) pairs which took the lazy softmax's exact pass (*exact_passes_host; of B * heads * ceil(N / 32) *
- * ceil(N / 64) pairs in all).  Same results; SYNCHRONISES the stream; a few % slower than the product kernel (the counter
- * costs its hot loop registers), which is why the product kernel does not carry it.  bench.py's `attention_ramp` leg. */
+ * (wave, 64-key tile) pairs whose softmax reference had to ADVANCE before the tile's exponentials (*exact_passes_host; of
+ * B * heads * ceil(N / 32) * ceil(N / 64) pairs in all; until round 3 the count was of tiles redone after an overflow).
+ * Same results; SYNCHRONISES the stream.  bench.py's `attention_ramp` leg. */
 int pope_attention_planes_diag_f32(const void* qkv_planes, void* out_planes, int B, int N, int heads, long long* exact_passes_host,
                                    void* stream);
 

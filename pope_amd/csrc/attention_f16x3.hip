@@ -479,20 +479,22 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         }
     };
     // Online softmax of (c0, c1) with a LAZY reference (log2 domain): p' = 2^(s - ref), where ref = (the row maximum
-    // as of the last exact pass) - 8, not this tile's.  On gfx950 every VALU instruction issued between the MFMAs takes
+    // as of the last advance) - 8, not this tile's.  On gfx950 every VALU instruction issued between the MFMAs takes
     // about two cycles from the matrix pipe (DESIGN.md finding 4), so what can go, goes:
-    //   * the per-tile row maximum (16 v_max3, the swap across the two 32-lane halves, its wait states) and the
-    //     unconditional rescale of o and l (21 multiplies): a tile whose scores stay below ref + 16 needs neither —
-    //     p' < 2^16 still splits into f16 (hi, lo), and with 2^8 of headroom under the running maximum the split keeps
-    //     fp32 accuracy;
+    //   * the unconditional rescale of o and l (21 multiplies) and the cross-half exchange of the row maximum: a tile
+    //     whose scores stay below ref + 16 needs neither — p' < 2^16 still splits into f16 (hi, lo), and with 2^8 of
+    //     headroom under the running maximum the split keeps fp32 accuracy;
     //   * the subtraction: the score MFMAs start from C = -ref (nref), so s - ref is what they deliver.
-    // The tile's probability sum (computed anyway) tells whether that may have failed: any p' >= 65 504 makes it >= 65 504.
-    // Then the cold path looks at the probabilities themselves, and only for a real overflow — or NaN/inf — `redo_tile`
-    // recomputes the tile's raw scores from its K stage (still resident) and
-    // takes the exact pass: true row maximum, new reference, o and l rescaled, and the next tile's scores (already
-    // computed against the old reference) shifted to the new one.  Results do not depend on which path ran beyond fp32
-    // rounding; the speed does (diffuse attention rows: exact pass on tile 0 only).
-    constexpr float LAZY_HEADROOM = 8.0f, LAZY_LIMIT = 65504.0f;
+    // LOOK-AHEAD (round 4).  Whether a tile fits is decided BEFORE its exponentials, from its biased scores themselves:
+    // the scores of tile t + 1 are complete when phase 1 of iteration t ends, and their per-lane maximum (16 v_max3) is
+    // taken behind the P.V MFMAs of iteration t.  If no lane reaches 2^16 the tile runs on the old reference; otherwise
+    // `advance` — between the iterations, nothing recomputed — takes the true row maximum (one cross-half swap), moves the
+    // reference of the rows that need it to (their maximum - 8), rescales their o and l and re-biases the waiting scores.
+    // Rounds 2-3 instead detected the overflow AFTER the exponentials (from the tile's probability sum) and then
+    // recomputed the tile's scores from its K stage (24 MFMAs) for an exact pass: one more tile's worth of time per
+    // event, +49 % on scores that climb by 9 log2 units per tile; now +15 %, and the hot loop has no redo path hanging on
+    // its register allocation.  Results do not depend on which path ran beyond fp32 rounding.
+    constexpr float LAZY_HEADROOM = 8.0f, LAZY_LIMIT_LOG2 = 15.99f;   // 2^15.99 < 65 504, the largest f16
     f32x2 sm_ls = {0.f, 0.f};
     // true row maximum of the RAW scores (c0, c1) -> new reference; o and l rescaled; returns old - new reference
     auto exact_prepare = [&](const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {
@@ -542,56 +544,35 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         if (slot % 3 != 2)
             exp_pair((slot / 3) * 2 + slot % 3, sb[decltype(ptag)::value][0], sb[decltype(ptag)::value][1], std::true_type{});
     };
-    // the exact pass for tile `tile` (its K rows in stage st): scores again, true maximum, rescale, probabilities
-    auto redo_tile = [&](int tile, int st, auto ptag) __attribute__((always_inline)) {
-        f32x16& c0 = sb[decltype(ptag)::value][0];
-        f32x16& c1 = sb[decltype(ptag)::value][1];
-        f32x16 d0, d1;
-        KFrag kf;
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            read_kfrag(st, kg, kf);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) qk_step(kg, j, kf, d0, d1, std::false_type{});
-        }
-        if ((tile + 1) * KT > N) mask_tail(tile, d0, d1);
-        // hand the scores back IN the registers the fast pass uses ("+v" ties them): a plain assignment makes the
-        // register allocator merge the two paths with copies on the fast one.  The s_nops: XDL write -> VALU read
-        // wait states the hazard recognizer does not add for inline asm
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(d0), "+v"(d1));
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            asm volatile("v_mov_b32 %0, %1" : "+v"(c0[i]) : "v"(d0[i]));
-            asm volatile("v_mov_b32 %0, %1" : "+v"(c1[i]) : "v"(d1[i]));
-        }
-        if constexpr (DIAG)
-            if (lane == 0) (void)__hip_atomic_fetch_add(&g_attn_exact_passes, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float delta = exact_prepare(c0, c1);
-        sm_ls = f32x2{0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 16; ++i) exp_pair(i, c0, c1, std::false_type{});
-        // the next tile's scores were computed against the old reference (garbage after the last tile: harmless)
-        f32x16& n0 = sb[decltype(ptag)::value ^ 1][0];
-        f32x16& n1 = sb[decltype(ptag)::value ^ 1][1];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { n0[i] += delta; n1[i] += delta; }
+    // per-lane maximum of the waiting (biased) scores, one v_max3 per slot (two values each); slot 0 starts the chain
+    float la_mt = 0.f;
+    auto lookahead_slice = [&](int slot, const f32x16& n0, const f32x16& n1) __attribute__((always_inline)) {
+        if (slot == 0) la_mt = vmax3(n0[0], n1[0], n0[1]);
+        else if (slot < 15) la_mt = vmax3(la_mt, n1[slot], n0[slot + 1]);
+        else if (slot == 15) la_mt = __builtin_fmaxf(la_mt, n1[15]);   // compiler-generated: feeds the ballot / the swap
     };
-    // after the fast pass of a tile: did every probability fit?  (wave-uniform branch; !(x < limit) also catches NaN)
-    auto settle = [&](int tile, int st, auto ptag) __attribute__((always_inline)) {
-        const float tile_sum = sm_ls[0] + sm_ls[1];
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(tile_sum < LAZY_LIMIT)) != 0, 0)) {
-            // the sum of a lane's 32 probabilities is a conservative test (flat rows reach it 5 log2 units early): on this
-            // cold path look at the probabilities themselves (still in c0, c1) and redo only if one left the f16 range
-            const f32x16& c0 = sb[decltype(ptag)::value][0];
-            const f32x16& c1 = sb[decltype(ptag)::value][1];
-            float mt = vmax3(c0[0], c1[0], c0[1]);
+    // the waiting scores (n0, n1) reach 2^16 under the current reference somewhere in this wave: move the reference of
+    // those rows.  Cold path; everything is changed IN PLACE (no value is handed back through new registers).
+    auto advance = [&](f32x16& n0, f32x16& n1) __attribute__((always_inline)) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(la_mt < LAZY_LIMIT_LOG2)) != 0, 0)) {
+            if constexpr (DIAG)
+                if (lane == 0) (void)__hip_atomic_fetch_add(&g_attn_exact_passes, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float ma, mb;
+            pope_xor32_pair(la_mt, ma, mb);                       // the row lives in lanes l and l ^ 32
+            const float over = __builtin_fmaxf(__builtin_fmaxf(ma, mb) - LAZY_HEADROOM, 0.f);   // rows that fit: 0
+            const float delta = -over, alpha = __builtin_amdgcn_exp2f(delta);                  // alpha = 1 for them
+            const float nr = nref[0] + delta;                     // -(ref + over)
 #pragma unroll
-            for (int i = 1; i < 15; ++i) mt = vmax3(mt, c1[i], c0[i + 1]);
-            mt = __builtin_fmaxf(mt, c1[15]);
-            if (__builtin_amdgcn_ballot_w64(!(mt < LAZY_LIMIT) || !(tile_sum == tile_sum)) != 0) redo_tile(tile, st, ptag);
+            for (int i = 0; i < 16; ++i) nref[i] = nr;
+            l_run = l_run * alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { n0[i] += delta; n1[i] += delta; }
         }
-        l_run += sm_ls;
     };
+    // after the softmax slices of a tile: its probability sum joins the running denominator
+    auto settle = [&]() __attribute__((always_inline)) { l_run += sm_ls; };
     // ---- phase 1: S^T(tile in stage st_next) -> (n0, n1), each MFMA followed by a slice of the softmax of (c0, c1)
     auto phase1 = [&](int st_next, auto ptag) {
         f32x16& n0 = sb[decltype(ptag)::value ^ 1][0];
@@ -620,8 +601,9 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
         for (int e = 0; e < 4; ++e) pv4[e] = sb[decltype(ptag)::value][u][8 * s2 + 4 * half + e];
         split4(pv4, hi, lo);
     };
-    auto phase2 = [&](int st, int st_write, auto split_tag, const u32x4 (&pregs)[4], auto ptag) {
+    auto phase2 = [&](int st, int st_write, auto split_tag, const u32x4 (&pregs)[4], auto ptag, auto look_tag) {
         constexpr bool SPLIT_KV = decltype(split_tag)::value;
+        constexpr bool LOOK = decltype(look_tag)::value;   // the scores of the next tile wait in the other buffer
         const _Float16* Vh = lds + st * STAGE_H + 2 * K_PLANE;
         const _Float16* Vl = Vh + V_PLANE;
         f16x4 h0[2], l0[2], h1[2], l1[2];
@@ -651,6 +633,7 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
                 if (j == 1) split_group(g + 1, 0, h0[nxt], l0[nxt], ptag);
                 if (j == 3) split_group(g + 1, 1, h1[nxt], l1[nxt], ptag);
             }
+            if (LOOK && i % 3 != 1) lookahead_slice(i - (i + 1) / 3, sb[decltype(ptag)::value ^ 1][0], sb[decltype(ptag)::value ^ 1][1]);
             if (SPLIT_KV && j == 5) {  // a quarter of tile t+2's staging per 16-key group
                 if constexpr (IN_PLANES) {
                     write_chunk(st_write, g, pregs);
@@ -712,9 +695,11 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
     auto steady = [&](u32x4 (&regs)[4], auto ptag) {
         ATTN_STAMP(t, 0);
         phase1(st_next, ptag);
-        settle(t, st_cur, ptag);
+        settle();
         ATTN_STAMP(t, 1);
-        phase2(st_cur, st_write, std::true_type{}, regs, ptag);  // also moves tile t+2 from registers into stage st_write
+        // also moves tile t+2 from registers into stage st_write, and takes the look-ahead maximum of tile t+1's scores
+        phase2(st_cur, st_write, std::true_type{}, regs, ptag, std::true_type{});
+        advance(sb[decltype(ptag)::value ^ 1][0], sb[decltype(ptag)::value ^ 1][1]);
         if constexpr (IN_PLANES) load_planes(t + 4, regs);
         else if (t + 3 < nkt) load_kv(t + 3);
         ATTN_STAMP(t, 2);
@@ -735,17 +720,18 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_pipe_kernel(const float* __r
             phase1(st_next, ptag);
             mask_tail(t + 1, sb[P ^ 1][0], sb[P ^ 1][1]);
             asm volatile("" : "+v"(sb[P ^ 1][0]), "+v"(sb[P ^ 1][1]));
-            settle(t, st_cur, ptag);
-            phase2(st_cur, st_write, std::false_type{}, pa, ptag);
+            settle();
+            phase2(st_cur, st_write, std::false_type{}, pa, ptag, std::true_type{});   // look-ahead over the masked scores
+            advance(sb[P ^ 1][0], sb[P ^ 1][1]);
             rotate();
             ++t;
             softmax_only(Q{});  // last tile
-            settle(t, st_cur, Q{});
-            phase2(st_cur, st_write, std::false_type{}, pa, Q{});
+            settle();
+            phase2(st_cur, st_write, std::false_type{}, pa, Q{}, std::false_type{});
         } else {
             softmax_only(ptag);
-            settle(t, st_cur, ptag);
-            phase2(st_cur, st_write, std::false_type{}, pa, ptag);
+            settle();
+            phase2(st_cur, st_write, std::false_type{}, pa, ptag, std::false_type{});
         }
     };
     if (t & 1) tail(P1{});

@@ -227,6 +227,44 @@ def test_attention_lazy_reference_paths(dev, hip_lib, step, planes):
     assert err < 2e-5, err
 
 
+def test_attention_reference_advances_row_by_row(dev, hip_lib):
+    """Look-ahead reference advance (attention_f16x3.hip, round 4): inside one 32-query wave only SOME rows see scores that
+    climb out of the f16 range of their reference — rows that look along u — while their neighbours (random queries) stay
+    diffuse.  The advancing rows must move (their o / l rescaled, the waiting scores re-biased) and the others must not
+    (alpha = 1 exactly); a late single outlier key (an attention sink in the LAST tile) and a sink in the first tile are in
+    the same launch.  fp64 reference on the values the planes hold."""
+    import ctypes as C
+    from pope_amd import _lib
+    B, N, heads = 2, 700, 6
+    D = heads * 64
+    g = torch.Generator().manual_seed(7)
+    qkv = torch.randn(B, N, 3, heads, 64, generator=g) * 0.4
+    u = torch.randn(heads, 64, generator=g)
+    u = u / u.norm(dim=-1, keepdim=True) * 8.0
+    ramp = torch.arange(N, dtype=torch.float32) / 64.0 * (9.0 / 8.0)
+    qkv[0, 0::3, 0] += u                                  # every third query of image 0 looks along u ...
+    qkv[0, :, 1] += u * ramp[:, None, None]               # ... and sees keys whose score climbs 13 log2 units per tile
+    qkv[1, :, 0] += u * 0.5
+    qkv[1, 3, 1] += u * 2.0                               # image 1: a sink key in the first tile,
+    qkv[1, N - 5, 1] += u * 6.0                           # and a far stronger one in the last (ragged) tile
+    pl = _lib.to_planes(qkv.reshape(B * N, 3 * D).contiguous(), _lib.PLANES_ACT_SCALE)
+    seen = _lib.from_planes(pl, _lib.PLANES_ACT_SCALE).double().reshape(B, N, 3, heads, 64)
+    q, k, v = seen.permute(2, 0, 3, 1, 4)
+    want = (((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B * N, D)
+    pin = pl.to(dev)
+    pout = torch.zeros(B * N, D // 32, 2, 32, dtype=torch.float16, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert hip_lib.pope_attention_planes_f32(C.c_void_p(pin.data_ptr()), C.c_void_p(pout.data_ptr()), B, N, heads, st) == 0
+    got = _lib.from_planes(pout.cpu(), _lib.PLANES_ACT_SCALE).double()
+    err = float(((got - want).abs() / (1.0 + want.abs())).max())
+    n_adv = C.c_longlong(0)
+    assert hip_lib.pope_attention_planes_diag_f32(C.c_void_p(pin.data_ptr()), C.c_void_p(pout.data_ptr()), B, N, heads, C.byref(n_adv), st) == 0
+    pairs = B * heads * (-(-N // 32)) * (-(-N // 64))
+    print(f"row-by-row advance: max scaled |err| vs fp64 = {err:.2e}; {n_adv.value} advances in {pairs} (wave, tile) pairs")
+    assert err < 2e-5 and 0 < n_adv.value < pairs
+    assert torch.equal(_lib.from_planes(pout.cpu(), _lib.PLANES_ACT_SCALE).double(), got)    # the counting twin: same bits
+
+
 def test_cls_cosine_and_top3(dev, golden_dir):
     import os
     from pope_amd import ops
