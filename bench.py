@@ -604,7 +604,8 @@ def config5_leg(device, iters=3):
                               window_size=14, out_chans=256)
         enc.load_state_dict(synth.synthetic_sam_encoder_state_dict(seed=0, global_idx=gidx), strict=True)
         enc = enc.eval().to(device)
-        x = synth.synthetic_images(4, 1024, 1024, seed=3, device=device)
+        SB = 8   # images per launch sequence (ImageEncoderViT.max_batch): 128 row tiles of 256 for the long-K GEMMs
+        x = synth.synthetic_images(SB, 1024, 1024, seed=3, device=device)
         n, dim, hd, heads = 4096, 1280, 80, 16
         lin = n * (768 * dim + 32 * 12 * dim * dim + dim * 256 + 9 * 256 * 256)
         att = 4 * heads * (n * n * 2 * hd + n * 128 * hd) + 28 * 25 * heads * (196 * 196 * 2 * hd + 196 * 28 * hd)
@@ -613,9 +614,9 @@ def config5_leg(device, iters=3):
         for prec, key in (("f16x3", "sam_vit_h_encoder"), ("f16", "sam_vit_h_encoder_f16")):
             enc.precision = prec   # f16x3: fp32-level results; f16: config 5's dtype, one MFMA per product
             ms, ok = timed(enc, x)
-            out[key] = {"value": round(4e3 / ms, 1), "unit": "images/s", "batch": 4, "image": [1024, 1024], "dtype": prec,
-                        "ms_per_image": round(ms / 4, 3), "tflops_algorithmic": round(fl * 4 / ms / 1e9, 1),
-                        "frac_of_f16_mfma_peak_executed": round((3 if prec == "f16x3" else 1) * fl * 4 / ms / 1e9 / PEAK_F16_MFMA_TFLOPS, 4),
+            out[key] = {"value": round(SB * 1e3 / ms, 1), "unit": "images/s", "batch": SB, "image": [1024, 1024], "dtype": prec,
+                        "ms_per_image": round(ms / SB, 3), "tflops_algorithmic": round(fl * SB / ms / 1e9, 1),
+                        "frac_of_f16_mfma_peak_executed": round((3 if prec == "f16x3" else 1) * fl * SB / ms / 1e9 / PEAK_F16_MFMA_TFLOPS, 4),
                         "verified": ok}
             y = enc(x[:1])
             if ref_out is None:

@@ -558,8 +558,10 @@ int pope_launch_planes16(const GemmParams& g, hipStream_t stream) {
     if (g.epilogue == EPI_SAM_QKV) {
         if (!g.sam_q || !g.sam_k || !g.sam_v || !g.sam_rowmap || g.sam_hd <= 0 || (g.sam_hd & 3) || (g.sam_dim & 63) || g.N != 3 * g.sam_dim)
             return POPE_ERR_ARG;
+        if (g.plain && pope_plain256_supported(g)) return pope_launch_plain256(g, stream);
         return g.plain ? launch16<EPI_SAM_QKV, true, false, true>(g, stream) : launch16<EPI_SAM_QKV, true, false, false>(g, stream);
     }
+    if (g.plain && pope_plain256_supported(g)) return pope_launch_plain256(g, stream);   // long-K shapes at large M: gemm_plain.hip
     if (g.plain) {   // single-product f16 (SAM encoder, precision "f16"): the four forms that path uses
         if (g.epilogue == EPI_BIAS && !out_planes) return launch16<EPI_BIAS, false, false, true>(g, stream);
         if (g.epilogue == EPI_BIAS_GELU && out_planes) return launch16<EPI_BIAS_GELU, true, false, true>(g, stream);

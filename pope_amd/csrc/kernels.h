@@ -99,6 +99,10 @@ int pope_launch_sim_f16x3_planes(const GemmParams& g, hipStream_t stream);  // E
 // residual GEMM + the following LayerNorm in one kernel (gemm_rowln.hip; N = 384 only: `supported` says)
 bool pope_gemm_rowln_supported(const GemmParams& g);
 int pope_launch_gemm_rowln(const GemmParams& g, hipStream_t stream);
+// plain-f16 long-K mainloop (gemm_plain.hip: 256-row tiles, LDS-direct staging) for the GemmParams::plain shapes it serves;
+// same results as pope_launch_planes16 on them
+bool pope_plain256_supported(const GemmParams& g);
+int pope_launch_plain256(const GemmParams& g, hipStream_t stream);
 // the v_mfma_f32_16x16x32_f16 mainloop (gemm_planes.hip) behind both of the above; arguments already validated
 int pope_launch_planes16(const GemmParams& g, hipStream_t stream);
 constexpr float K_PLANES_ACT_SCALE = 8.0f, K_PLANES_W_SCALE = 256.0f;  // == POPE_PLANES_*_SCALE of pope_hip.h

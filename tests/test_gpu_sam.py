@@ -219,3 +219,21 @@ def test_default_norm_layer_eps_1e5(hip_lib):
         want = sam_encoder_ref.forward(sd, x, 4, 14, (1,), block_eps=1e-5)
         other = sam_encoder_ref.forward(sd, x, 4, 14, (1,), block_eps=1e-6)
     assert float((got - want).abs().max()) <= 1e-4 and float((got - other).abs().max()) > float((got - want).abs().max())
+
+
+def test_f16_mode_is_batch_invariant_across_the_gemm_switch(hip_lib, golden_dir):
+    """precision "f16": the small encoder (grid 16: 256 token rows per image) alone runs its Linear layers on the 128 x 128 tile
+    kernel, a batch of eight (2 048 rows) on gemm_plain.hip's 256-row tiles — including the QKV projection whose epilogue
+    writes the attention operand rows through the window row map (EPI_SAM_QKV).  Same accumulation order, same epilogue
+    arithmetic: image k of the batch is bit-equal to its own run."""
+    from pope_amd import synth
+    fx = np.load(os.path.join(golden_dir, "sam_hd80_256.npz"))
+    m, _, _ = build(fx)
+    m.precision = "f16"
+    m.max_batch = 8
+    img = int(fx["arch"][3])
+    x = synth.synthetic_images(8, img, img, seed=31).cuda()
+    big = m(x)
+    for k in (0, 3, 7):
+        assert torch.equal(m(x[k:k + 1])[0], big[k]), k
+    assert bool(torch.isfinite(big).all())

@@ -222,3 +222,21 @@ def test_in_place_weight_edits_refresh_the_derived_planes(hip_lib, sd0):
     y1 = m(x, is_training=True)["x_norm_patchtokens"]
     fresh = load_dinov2_model(state_dict=sd1).cuda()
     assert not torch.equal(y0, y1) and torch.equal(y1, fresh(x, is_training=True)["x_norm_patchtokens"])
+
+
+def test_f16_mode_is_batch_invariant_across_the_gemm_switch(hip_lib, sd0):
+    """precision "f16" has two GEMM mainloops: gemm_planes16_kernel's 128 x 128 tiles (small M) and gemm_plain.hip's 256-row tiles
+    with LDS-direct staging (M >= 2 048; round 4).  Both accumulate every output in the same order and share the epilogue
+    arithmetic: an image must come out bit-identical alone (257 rows: the tile kernel) and inside a batch of nine (2 313 rows:
+    the new kernel for QKV -> fp32, FC1 . GELU -> f16, proj / FC2 + residual)."""
+    from pope_amd import synth
+    from pope_amd.dinov2_utils import load_dinov2_model
+    m = load_dinov2_model(state_dict=sd0).to("cuda:0")
+    m.precision = "f16"
+    x = synth.synthetic_images(9, 224, 224, seed=77).cuda()
+    big = m(x, is_training=True)
+    for k in (0, 4, 8):
+        one = m(x[k:k + 1], is_training=True)
+        for key in ("x_norm_clstoken", "x_norm_patchtokens", "x_prenorm"):
+            assert torch.equal(one[key][0], big[key][k]), (k, key)
+    assert m.overflow_events == 0 and bool(torch.isfinite(big["x_prenorm"]).all())
