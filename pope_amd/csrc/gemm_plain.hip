@@ -64,7 +64,10 @@ __device__ __forceinline__ f32x2 pl_gelu_pair(f32x2 x) {
 }
 
 // NWN: waves along N (4: 256-column tiles, a wave owns 128 x 64; 2: 128-column tiles, a wave owns 64 x 64)
-template <int EPI, bool OUT_F16, int NWN>
+// X3: the operands are f16x3 PLANES (a row's K-step = [32 hi | 32 lo] halves — the same 128 bytes per row and K-step as 64
+// plain f16 columns, so staging, LDS image and fragment addresses are shared): three MFMAs per product (lo.hi, hi.lo, hi.hi,
+// gemm_planes.hip's order), planes output.
+template <int EPI, bool OUT_F16, int NWN, bool X3 = false>
 __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmParams g) {
     constexpr int BN = 64 * NWN, SUB = NWN / 2, ROWS = PL_BM + BN, NST = pl_stages(BN);
     constexpr int STAGE = ROWS * 64;   // halves per stage: 128-byte rows, A rows then W rows
@@ -129,31 +132,64 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
         // half's four W fragments).  A wave that reads a fragment right before its MFMAs waits out the LDS latency every
         // time: the activation fragment of unit u + 3 is requested right behind the MFMAs of unit u (four slots), the W
         // fragments of the second half three units before it starts.  Scheduling fences pin the order of MFMAs and LDS reads.
-        constexpr int UPH = SUB * 4, U = 2 * UPH;
-        f16x8 wf[2][4], af[4];
-        auto rd_a = [&](int u) {
-            const int h = u / UPH, r = u % UPH;   // r = sub-tile * 4 + row block: rows 16 r of this wave's 64 SUB
-            af[u & 3] = *reinterpret_cast<const f16x8*>(S + a_row + r * (16 * 64) + (h ? swz1 : swz0));
-        };
-        auto rd_w = [&](int h) {
+        if constexpr (X3) {
+            // planes: a unit = one 16-row block = its (hi, lo) fragment pair and twelve MFMAs against the K-step's four (hi, lo) W
+            // fragment pairs; the pair of unit r + 2 is requested behind the MFMAs of unit r (three slots)
+            constexpr int UX = SUB * 4;
+            f16x8 wh[4], wl[4], ah[3], al[3];
+            auto rd_ax = [&](int r) {
+                ah[r % 3] = *reinterpret_cast<const f16x8*>(S + a_row + r * (16 * 64) + swz0);
+                al[r % 3] = *reinterpret_cast<const f16x8*>(S + a_row + r * (16 * 64) + swz1);
+            };
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) wf[h][ni] = *reinterpret_cast<const f16x8*>(S + w_row + ni * (16 * 64) + (h ? swz1 : swz0));
-        };
-        rd_w(0);
-        rd_a(0);
-        rd_a(1);
-        rd_a(2);
-        PL_FENCE();
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int h = u / UPH, r = u % UPH;
-            // accumulators hold C^T (A-operand = W fragment, B-operand = activation fragment): gemm_planes.hip
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[r >> 2][r & 3][ni] = pl_mfma(wf[h][ni], af[u & 3], acc[r >> 2][r & 3][ni]);
+            for (int ni = 0; ni < 4; ++ni) {
+                wl[ni] = *reinterpret_cast<const f16x8*>(S + w_row + ni * (16 * 64) + swz1);
+                wh[ni] = *reinterpret_cast<const f16x8*>(S + w_row + ni * (16 * 64) + swz0);
+            }
+            rd_ax(0);
+            rd_ax(1);
             PL_FENCE();
-            if (u == UPH - 3) rd_w(1);
-            if (u + 3 < U) rd_a(u + 3);
+#pragma unroll
+            for (int r = 0; r < UX; ++r) {
+                f32x4(&c)[4] = acc[r >> 2][r & 3];
+                // small terms first, term-major over the four accumulators: the order of gemm_planes16_kernel (bit-identical)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) c[ni] = pl_mfma(wl[ni], ah[r % 3], c[ni]);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) c[ni] = pl_mfma(wh[ni], al[r % 3], c[ni]);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) c[ni] = pl_mfma(wh[ni], ah[r % 3], c[ni]);
+                PL_FENCE();
+                if (r + 2 < UX) rd_ax(r + 2);
+                PL_FENCE();
+            }
+        } else {
+            constexpr int UPH = SUB * 4, U = 2 * UPH;
+            f16x8 wf[2][4], af[4];
+            auto rd_a = [&](int u) {
+                const int h = u / UPH, r = u % UPH;   // r = sub-tile * 4 + row block: rows 16 r of this wave's 64 SUB
+                af[u & 3] = *reinterpret_cast<const f16x8*>(S + a_row + r * (16 * 64) + (h ? swz1 : swz0));
+            };
+            auto rd_w = [&](int h) {
+    #pragma unroll
+                for (int ni = 0; ni < 4; ++ni) wf[h][ni] = *reinterpret_cast<const f16x8*>(S + w_row + ni * (16 * 64) + (h ? swz1 : swz0));
+            };
+            rd_w(0);
+            rd_a(0);
+            rd_a(1);
+            rd_a(2);
             PL_FENCE();
+    #pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int h = u / UPH, r = u % UPH;
+                // accumulators hold C^T (A-operand = W fragment, B-operand = activation fragment): gemm_planes.hip
+    #pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[r >> 2][r & 3][ni] = pl_mfma(wf[h][ni], af[u & 3], acc[r >> 2][r & 3][ni]);
+                PL_FENCE();
+                if (u == UPH - 3) rd_w(1);
+                if (u + 3 < U) rd_a(u + 3);
+                PL_FENCE();
+            }
         }
     }
 
@@ -228,9 +264,18 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
             for (int i = 0; i < 8; ++i) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(&E[(elr + 4 * i) * EPI_ST + ec4]);
                 const unsigned off = (row0 + 4 * i) * c_row_bytes;
+                [[maybe_unused]] auto store_planes = [&](f32x4 val) {   // planes row: per 32-column chunk [32 hi | 32 lo] halves, value * 8
+                    f16x4 hi, lo;
+                    pope_amax4x2(amax, val);
+                    pope_split4(val * PL_A_SCALE, hi, lo);
+                    const unsigned o = col_ok ? off + unsigned((col >> 5) * 128 + (col & 31) * 2) : DROP;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rc, o, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rc, o + 64u, 0, 2);
+                };
                 if constexpr (EPI == EPI_BIAS) {
                     v = v * inv + bias;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, col_ok ? off + unsigned(col) * 4u : DROP, 0, 2);
+                    if constexpr (X3 && OUT_F16) store_planes(v);
+                    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, col_ok ? off + unsigned(col) * 4u : DROP, 0, 2);
                 } else if constexpr (EPI == EPI_SAM_QKV) {
                     v = (v * inv + bias) * sq_scale;
                     pope_amax4x2(amax, v);
@@ -240,7 +285,9 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
                     v = v * inv + bias;
                     const f32x2 g01 = pl_gelu_pair(f32x2{v[0], v[1]}), g23 = pl_gelu_pair(f32x2{v[2], v[3]});
                     v = f32x4{g01[0], g01[1], g23[0], g23[1]};
-                    if constexpr (OUT_F16) {   // f16 row-major, value * 8
+                    if constexpr (X3 && OUT_F16) {
+                        store_planes(v);
+                    } else if constexpr (OUT_F16) {   // f16 row-major, value * 8
                         pope_amax4x2(amax, v);
                         const f16x4 hh = __builtin_convertvector(v * PL_A_SCALE, f16x4);
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), rc, col_ok ? off + unsigned(col) * 2u : DROP, 0, 2);
@@ -279,7 +326,33 @@ int launch_plain_n(const GemmParams& g, hipStream_t stream) {
     return g.N >= 512 ? launch_plain<EPI, OUT_F16, 4>(g, stream) : launch_plain<EPI, OUT_F16, 2>(g, stream);
 }
 
+template <int EPI>
+int launch_x3(const GemmParams& g, hipStream_t stream) {
+    static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
+    if (!pope_opt_in_lds(gemm_plain256_kernel<EPI, true, 4, true>, pl_lds_bytes(256), lds_ok)) return POPE_ERR_LAUNCH;
+    const int tiles = ((g.M + PL_BM - 1) / PL_BM) * ((g.N + 255) / 256);
+    hipLaunchKernelGGL((gemm_plain256_kernel<EPI, true, 4, true>), dim3(tiles), dim3(PL_THREADS), pl_lds_bytes(256), stream, g);
+    return pope_check_launch();
+}
+
 }  // namespace
+
+// f16x3 planes -> planes (QKV, FC1 of the ViT blocks) on the 256 x 256 LDS-direct mainloop: the shapes it serves
+bool pope_wide_x3_supported(const GemmParams& g) {
+    if (g.plain || !g.a_pl || !g.w_pl || !g.c_pl || g.conv_cch > 0 || g.nbatch > 1) return false;
+    if (g.epilogue != EPI_BIAS && g.epilogue != EPI_BIAS_GELU) return false;
+    if (g.N < 512 || (g.N & 63) || g.K < 64 || (g.K & 31) || (g.lda & 31) || (g.ldw & 31) || (g.ldc & 31)) return false;
+    // 256-row tiles must fill the chip for several rounds: one workgroup per CU, nothing runs under a tile's epilogue
+    return size_t((g.M + PL_BM - 1) / PL_BM) * ((g.N + 255) / 256) >= size_t(4) * pope_cu_count();
+}
+
+int pope_launch_wide_x3(const GemmParams& g, hipStream_t stream) {
+    if (!pope_wide_x3_supported(g)) return POPE_ERR_ARG;
+    if (size_t(g.M + PL_BM) * g.lda * 4 >= (size_t(1) << 32) || size_t(g.N + 256) * g.ldw * 4 >= (size_t(1) << 32) ||
+        size_t(g.M + PL_BM) * g.ldc * 4 >= (size_t(1) << 32) - 512)
+        return POPE_ERR_ARG;
+    return g.epilogue == EPI_BIAS_GELU ? launch_x3<EPI_BIAS_GELU>(g, stream) : launch_x3<EPI_BIAS>(g, stream);
+}
 
 bool pope_plain256_supported(const GemmParams& g) {
     if (!g.plain || !g.a_pl || !g.w_pl || g.conv_cch > 0 || g.nbatch > 1) return false;

@@ -571,6 +571,9 @@ int pope_launch_planes16(const GemmParams& g, hipStream_t stream) {
             return launch16<EPI_CONV, false, true, true>(g, stream);
         return POPE_ERR_ARG;
     }
+    // planes -> planes at large M (QKV, FC1 of the ViT blocks): the 256 x 256 LDS-direct mainloop of gemm_plain.hip, same bits
+    // (round 4, same-box A/B inside bench.py: QKV 0.285 -> 0.273 ms, FC1 0.427 -> 0.351 ms, step 92.9 -> 89.0 ms)
+    if (pope_wide_x3_supported(g)) return pope_launch_wide_x3(g, stream);
     switch (g.epilogue) {
         case EPI_BIAS: return out_planes ? launch16<EPI_BIAS, true>(g, stream) : launch16<EPI_BIAS, false>(g, stream);
         case EPI_BIAS_GELU: return out_planes ? launch16<EPI_BIAS_GELU, true>(g, stream) : launch16<EPI_BIAS_GELU, false>(g, stream);

@@ -327,6 +327,47 @@ def test_linear_planes_ragged_shapes(dev, hip_lib, shape):
     _close(guard[:M].cpu(), F.linear(a.double(), w.double(), b.double()).float(), atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("N,epi", [(1152, 0), (1536, 1)])
+def test_wide_planes_gemm_equals_tile_kernel(dev, hip_lib, N, epi):
+    """Planes -> planes Linear layers at large M (QKV, FC1 . GELU of the ViT blocks) run on the 256 x 256 LDS-direct mainloop of
+    gemm_plain.hip (round 4); every other call on the 128 x 128 tile kernel.  Same accumulation order, same epilogue
+    arithmetic: the big call must equal, bit for bit, the same rows computed in pieces small enough to take the tile kernel —
+    with a ragged last row tile, and the range flag raised by the same outlier."""
+    import ctypes as C
+    from pope_amd import _lib
+    K = 384
+    M = 256 * (1024 // (-(-N // 256)) + 3) + 77          # a few more than 4 x CUs tiles of 256 x 256, ragged
+    g = torch.Generator().manual_seed(N)
+    a = torch.randn(M, K, generator=g) * 1.3
+    w, b = torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
+    a[M - 5, 7] = 3000.0                                  # one huge activation: an output beyond the f16 range of the planes
+    w[11, 7] = 3.0
+    ap = _lib.to_planes(a, _lib.PLANES_ACT_SCALE).to(dev)
+    wp = _lib.to_planes(w, _lib.PLANES_W_SCALE).to(dev)
+    bd = b.to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def run(rows_lo, rows_hi):
+        m = rows_hi - rows_lo
+        out = torch.zeros(m, N // 32, 2, 32, dtype=torch.float16, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        assert hip_lib.pope_linear_planes_f32(P(ap[rows_lo:rows_hi]), P(wp), P(bd), None, P(out), m, N, K, epi, None, None, P(flag), st) == 0
+        return out, int(flag.item())
+
+    big, flag_big = run(0, M)
+    step = 20000                                          # 79 row tiles x <= 6: far below the switch
+    parts = [run(lo, min(lo + step, M)) for lo in range(0, M, step)]
+    small = torch.cat([p[0] for p in parts])
+    assert torch.equal(big.view(torch.int16), small.view(torch.int16))
+    assert flag_big != 0 and flag_big == max(p[1] for p in parts)
+    rows = torch.arange(0, M - 8, 3001)
+    lin = F.linear(a[rows].double(), w.double(), b.double())
+    want = F.gelu(lin) if epi else lin
+    got = _lib.from_planes(big[rows.to(dev)].cpu(), _lib.PLANES_ACT_SCALE).double()
+    assert float((got - want).abs().max()) < 2e-5
+
+
 def test_layernorm_planes_and_split(dev, hip_lib):
     import ctypes as C
     from pope_amd import _lib
