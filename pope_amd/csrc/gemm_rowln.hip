@@ -6,13 +6,18 @@
 // read of x and a write of the planes at the HBM copy ceiling — disappear; x is normalised while its tile is still
 // in the producing workgroup's registers.
 //
-// A LayerNorm row needs all 384 columns, so the tile is a FULL ROW BLOCK: 128 rows x 384 columns, one workgroup of
-// 8 waves per CU (wave (wm, wn) owns 64 rows x 96 columns = 4 x 6 accumulator blocks of v_mfma_f32_16x16x32_f16).
-// Against the 128 x 128 kernel's two workgroups per CU this moves a third fewer bytes into LDS per MFMA (the W tile
-// is shared by twice the rows) and has one barrier domain; the 766 row tiles of a 64-image chunk are 2.99 rounds of
-// 256 CUs.  Operands are planes (gemm_planes.hip: the K-steps of consecutive tiles form one stream through a
-// double-buffered LDS, the next K-step's loads in flight in registers); LDS rows are the memory rows (128 B) with the
-// 16-byte chunk index XOR-ed with row & 7: conflict-free stores and 16-row fragment reads without padding, 2 x 64 KB.
+// A LayerNorm row needs all 384 columns, so the tile is a FULL ROW BLOCK: RM rows x 384 columns, one workgroup of 8 waves per
+// CU, persistent over the tile list.  Two geometries (RlGeo), chosen per launch by rounds x rows: 192 rows (wave (wm, wn) owns
+// 96 rows x 96 columns = 6 x 6 accumulator blocks of v_mfma_f32_16x16x32_f16; 511 tiles = 2 rounds for a 64-image chunk) and
+// 128 rows (64 x 96 per wave; 766 tiles = 3 rounds).  Operands are planes; a K-step's 128-byte row pieces go memory -> LDS
+// DIRECTLY (buffer_load ... lds, round 4: no staging registers, no ds_write; the VGPR -> LDS path was what this kernel's
+// K-step waited on, DESIGN.md finding 20), into unpadded rows whose 16-byte chunk index is XOR-ed with row & 7 on the source
+// side: conflict-free 16-row fragment reads; two stages of 64 / 72 KB, ONE barrier per K-step (LDS-scope fence only: a full
+// __syncthreads() would also wait for the epilogue's global stores).  The K-steps of consecutive tiles form one stream: the
+// first K-step of the next tile lands during the epilogue.  With no staging registers the kernel needs 150 - 220 VGPRs instead
+// of 256 with zero slack: every per-lane loop invariant is re-derived per K-step behind an opaque fence so that the allocator
+// has nothing to spill across the epilogue (a spill reload in the K loop waits for vmcnt(0), i.e. for the loads just issued).
+// Measured (same box, profiles/r04/rowln_dma_ab.txt): FC2+LN 0.400 -> 0.364 ms, proj+LN 0.159 -> 0.150, patch embed 0.288 -> 0.268.
 //
 // Epilogue, all in the accumulator layout (lane = row l & 15 of a block, four consecutive columns per register quad):
 // residual rows arrive as 16-byte loads and x replaces the accumulators in place; row sums go through two lane swaps
@@ -29,17 +34,36 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
-constexpr int RM = 128, RN = 384, RK = 32, RTH = 512;
-constexpr int NMI = 4;   // 16-row accumulator blocks per wave
+constexpr int RN = 384, RK = 32;
 constexpr int ROWB = 64;                          // halves per LDS row: 128 B, chunk-swizzled
-constexpr int STAGE_H = (RM + RN) * ROWB;          // halves per stage (A rows, then W rows): 64 KB
-constexpr size_t STATS_OFF = size_t(2) * STAGE_H * sizeof(_Float16);
-constexpr size_t CTAB_OFF = STATS_OFF + size_t(2) * 4 * RM * sizeof(float);       // after the two [4][128] row-sum tables
-constexpr size_t PF_OFF = CTAB_OFF + size_t(4) * RN * sizeof(float);              // + per-column constants
-constexpr size_t RL_LDS_BYTES = PF_OFF + size_t(8) * 256;                         // + landing pad of the residual prefetch = 143 360 B
+// Tile geometry: RM rows x 384 columns, NWM x 4 waves (a wave owns RM / NWM rows x 96 columns), one workgroup per CU
+template <int RM_, int NWM_> struct RlGeo {
+    static constexpr int RM = RM_, NWM = NWM_, NW = 4 * NWM, RTH = 64 * NW;
+    static constexpr int NMI = RM / NWM / 16;          // 16-row accumulator blocks per wave
+    static constexpr int STAGE_H = (RM + RN) * ROWB;   // halves per stage (A rows, then W rows): 64 KB / 72 KB
+    static constexpr size_t STATS_OFF = size_t(2) * STAGE_H * sizeof(_Float16);
+    static constexpr size_t CTAB_OFF = STATS_OFF + size_t(2) * 4 * RM * sizeof(float);   // after the two [4][RM] row-sum tables
+    static constexpr size_t PF_OFF = CTAB_OFF + size_t(4) * RN * sizeof(float);          // + per-column constants
+    static constexpr size_t LDS_BYTES = PF_OFF + size_t(NW) * 256;                       // + landing pads of the residual prefetch
+    // rows of a 16-row accumulator block that go through a wave's transposition buffer at a time: the NW buffers (100 floats
+    // per row) live in the stage the K loop has just left
+    static constexpr int EROWS = size_t(NW) * 16 * 100 * sizeof(float) <= size_t(STAGE_H) * sizeof(_Float16) ? 16 : 8;
+    static constexpr int AROWS = RM / NW, WROWS = RN / NW;   // rows a wave stages per K-step
+    static constexpr int NPF = (RM * 12 + RTH - 1) / RTH;    // residual-prefetch rounds per tile: one 128-byte line per lane each
+    static_assert(size_t(NW) * EROWS * 100 * sizeof(float) <= size_t(STAGE_H) * sizeof(_Float16), "transposition buffers must fit a stage");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS of a CU");
+    static_assert(WROWS % 8 == 0 && AROWS % 8 == 0 && RM == NWM * NMI * 16, "eight rows per staging instruction");
+};
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 constexpr float A_SCALE = K_PLANES_ACT_SCALE, W_SCALE = K_PLANES_W_SCALE;
 
+// lane id from the execution mask counters, seeded with an opaque zero: no input register (threadIdx.x held across the tile loop
+// gets spilled, and its reload in every K-step waits for vmcnt(0)), and not loop-invariant either (hoisted, the result is spilled too)
+__device__ __forceinline__ int pope_lane_id() {
+    unsigned z = 0;
+    asm volatile("" : "+s"(z));
+    return int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z)));
+}
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
@@ -64,23 +88,35 @@ __device__ unsigned long long g_rl_dbg[3][64];
 
 // LN_PLANES: LayerNorm output as activation planes (next GEMM's operand) or fp32 (final norm);
 // RES_TABLE: the residual row is row % res_mod of a [res_mod, 384] table (patch embed: cls / conv bias + pos)
-template <bool LN_PLANES, bool RES_TABLE>
-__global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g, int n_tiles) {
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a full workgroup-scope fence: the compiler puts
+// s_waitcnt vmcnt(0) in front of it, i.e. every global store of the epilogue in flight must be acknowledged before the wave
+// may even arrive (2 - 3 us per tile seam, and in the middle of the epilogue between the x stores and the second moment).
+// The LDS-direct loads are waited for explicitly where a stage is published.
+__device__ __forceinline__ void rl_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <class G, bool LN_PLANES, bool RES_TABLE>
+__global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g, int n_tiles) {
+    constexpr int RM = G::RM, NMI = G::NMI, RTH = G::RTH, STAGE_H = G::STAGE_H, EROWS = G::EROWS, AROWS = G::AROWS, WROWS = G::WROWS;
+    constexpr int WMR = 16 * NMI;                      // rows of a wave
+    constexpr int NIA = AROWS / 8, NIW = WROWS / 8;    // staging instructions per wave and K-step
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* lds = reinterpret_cast<_Float16*>(smem);
-    float* stats = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + STATS_OFF);   // [2][4][128]
+    float* stats = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + G::STATS_OFF);   // [2][4][RM]
     // per-column constants of the epilogue, staged once per workgroup (they would otherwise hold 96 registers or put
     // loads between the epilogue's stores): gamma / scale, bias * gamma, ln_w, ln_b
-    float* ctab = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + CTAB_OFF);     // [4][384]
-    constexpr int NLD = 8;   // 16-byte pieces per thread and K-step: 2 A rows + 6 W rows
+    float* ctab = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + G::CTAB_OFF);     // [4][384]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int l15 = lane & 15, q4 = lane >> 4;
-    const int prow = tid >> 3, pc = tid & 7;
     const int nk = g.K / RK;  // >= 2 (launcher)
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, unsigned(g.M) * unsigned(g.lda) * 4u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, unsigned(RN) * unsigned(g.ldw) * 4u, 0x00020000);
+    const unsigned lda4 = unsigned(g.lda) * 4u, ldw4 = unsigned(g.ldw) * 4u;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, unsigned(g.M) * lda4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, unsigned(RN) * ldw4, 0x00020000);
 
     // tile stream: full rounds by XCD-remapped id, the partial last round by raw blockIdx (gemm_planes.hip)
     const int grid = gridDim.x, full_rounds = n_tiles / grid;
@@ -100,40 +136,34 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
         ctab[2 * RN + tid] = g.ln_w[tid];
         ctab[3 * RN + tid] = g.ln_b[tid];
     }
-    // one VGPR offset per operand: the row block (64 i rows), the tile and the K-step travel in the scalar offset
-    const unsigned va = unsigned(prow) * unsigned(g.lda) * 4u + pc * 16u, vw = unsigned(prow) * unsigned(g.ldw) * 4u + pc * 16u;
-    const unsigned a64 = 64u * unsigned(g.lda) * 4u, w64 = 64u * unsigned(g.ldw) * 4u;
-    u32x4 r0[NLD];  // A rows, then W rows: the K-step after the one in the other LDS stage
-    int ld_ord = 0, ord = 0;
-    int ld_tile = first, ld_kt = 0;
-    auto load_next = [&]() {
-        const int lt = ld_tile < n_tiles ? ld_tile : n_tiles - 1;   // past the end: re-load, never consumed
-        const unsigned sa = unsigned(lt) * unsigned(RM) * unsigned(g.lda) * 4u + unsigned(ld_kt) * 128u, sw = unsigned(ld_kt) * 128u;
-        // A rows are read exactly once per launch (a tile spans all 384 columns): sc0 + nt keeps the 150 - 600 MB stream
-        // from displacing x / xn, which the next kernels re-read (+0.8 % on the step; the same hint on the residual
-        // loads, the x stores or the xn stores costs 1 - 10 %: measured, left at the default policy)
+
+    // ---- staging: memory -> LDS directly (buffer_load ... lds: no staging registers, no ds_write; gemm_plain.hip).  A
+    // wave-instruction moves 8 rows x 128 B; lane (r8 = lane >> 3, position lane & 7) fetches the 16-byte piece that belongs at
+    // its position of the swizzled row (piece c of row r sits at c ^ (r & 7); the rows of an instruction start at a multiple
+    // of 8).  The tile's row offset travels in the VGPR offset — the descriptor's range check then returns zeros for the rows
+    // past M of the last tile (a scalar offset is not range-checked) — W's row blocks and the K-step in the scalar offset.
+    // A rows are read exactly once per launch (a tile spans all 384 columns): sc0 + nt keeps the 150 - 600 MB stream from
+    // displacing x / xn, which the next kernels re-read.
+    // Per-lane loop invariants (staging offsets, fragment addresses) are RE-DERIVED from the lane id behind an opaque fence in
+    // every K-step (a dozen VALU instructions): held in registers across the tile loop they are the allocator's first spill
+    // candidates under the epilogue's pressure, and a spill reload inside the K loop waits for vmcnt(0) — for the loads just issued.
+    const unsigned a8 = 8u * lda4, w8 = 8u * ldw4;
+    auto dma = [&](int stage, int t, int kt_) {
+        int ln_ = pope_lane_id();
+        asm volatile("" : "+v"(ln_));
+        const int r8 = ln_ >> 3, piece = (ln_ & 7) ^ r8;
+        const int lt = t < n_tiles ? t : n_tiles - 1;   // past the end: re-load, never consumed
+        _Float16* S_ = lds + stage * STAGE_H;
+        const unsigned vt = unsigned(lt * RM + AROWS * wave + r8) * lda4 + unsigned(piece) * 16u, ko = unsigned(kt_) * 128u;
+        const unsigned vw0 = unsigned(WROWS * wave + r8) * ldw4 + unsigned(piece) * 16u;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) r0[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, va, sa + i * a64, 3);
+        for (int i = 0; i < NIA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(S_ + (AROWS * wave + 8 * i) * ROWB), 16, vt + i * a8, ko, 0, 3);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) r0[2 + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, vw, sw + i * w64, 0);
-        const int wrap = ++ld_kt == nk;
-        ld_kt = pope_uniform_select(wrap, 0, ld_kt);
-        ld_ord += wrap;
-        ld_tile = tile_of(ld_ord);
+        for (int i = 0; i < NIW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_ptr)(S_ + (RM + WROWS * wave + 8 * i) * ROWB), 16, vw0, ko + i * w8, 0, 0);
     };
-    // LDS image of a K-step: row r of an operand at r * 128 B, its 16-byte chunk c at chunk c ^ (r & 7)
-    const int wr_off = prow * ROWB + 8 * (pc ^ (prow & 7));   // rows prow + 64 i: same r & 7
-    auto write_stage = [&](int s) {
-        _Float16* S = lds + s * STAGE_H + wr_off;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(S + 64 * i * ROWB) = r0[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(S + (RM + 64 * i) * ROWB) = r0[2 + i];
-    };
-    // fragment t: rows 16 t + l15 of this wave's rows, logical chunk plane * 4 + q4
-    const int sw_hi = 8 * (q4 ^ (l15 & 7)), sw_lo = 8 * ((4 + q4) ^ (l15 & 7));
-    const int a_row = (wm * 64 + l15) * ROWB, w_row = (RM + wn * 96 + l15) * ROWB;
-    f32x4 acc[4][6];
+    f32x4 acc[NMI][6];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi)
@@ -147,32 +177,36 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(g.res), 0, unsigned(RES_TABLE ? g.res_mod : g.M) * unsigned(g.ldres) * 4u, 0x00020000);
 
-    // Residual prefetch.  The epilogue's 590 KB per tile (residual in, x and xn out) hit HBM from all 256 CUs at once while
-    // the K loops leave it idle; the residual third of that burst is pulled forward: during the K loop every lane touches
-    // three of the tile's 1 536 residual lines (one dword each, loaded straight into an LDS landing pad that nobody reads —
-    // no register, no wait), so the epilogue's residual loads find their lines in L2 / MALL.
-    lds_void_ptr pf_pad = (lds_void_ptr)(reinterpret_cast<char*>(smem) + PF_OFF + (tid >> 6) * 256);
-    const int pf_step = nk / 3;
+    // Residual prefetch.  The epilogue's bytes (residual in, x and xn out: 590 KB per 128 rows) hit HBM from all 256 CUs at
+    // once while the K loops leave it idle; the residual third of that burst is pulled forward: during the K loop every lane
+    // touches three of the tile's 12 RM residual lines (one dword each, loaded straight into an LDS landing pad that nobody
+    // reads — no register, no wait), so the epilogue's residual loads find their lines in L2 / MALL.
+    lds_void_ptr pf_pad = (lds_void_ptr)(reinterpret_cast<char*>(smem) + G::PF_OFF + wave * 256);
+    const int pf_step = nk / G::NPF;
     auto prefetch_res = [&](int tile_, int j) {
-        const unsigned L = unsigned(tid) + 512u * unsigned(j), row = L / 12u, piece = L - 12u * row;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rres, pf_pad, 4, (unsigned(tile_) * RM + row) * unsigned(RN) * 4u + piece * 128u, 0, 0, 0);
+        int t_ = wave * 64 + pope_lane_id();
+        asm volatile("" : "+v"(t_));
+        const unsigned L = unsigned(t_) + unsigned(RTH) * unsigned(j), row = L / 12u, pc = L - 12u * row;
+        // (lines past the tile's last — the final round of a geometry whose line count is no multiple of RTH — fall outside the descriptor)
+        const unsigned off = RM * 12 % RTH == 0 || L < unsigned(RM * 12) ? (unsigned(tile_) * RM + row) * unsigned(RN) * 4u + pc * 128u : 0xFFFFFF00u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rres, pf_pad, 4, off, 0, 0, 0);
     };
 
     int rl_si = 0;   // stamp index (dev builds)
     auto epilogue = [&](int tile, int free_stage) {
         const int m0 = tile * RM;
-        // per-wave transposition buffer in the LDS stage the K loop has just finished with (the other stage already holds
-        // the next tile's first K-step): 16 rows x 96 columns of this wave at a time, 400-byte pitch (conflict-free
+        // per-wave transposition buffer in the LDS stage the K loop has just finished with (the other stage is receiving
+        // the next tile's first K-step): EROWS rows x 96 columns of this wave at a time, 400-byte pitch (conflict-free
         // 16-byte pieces from the accumulator layout), read back as whole 128-byte lines: 8 lanes per line
-        float* wreg = reinterpret_cast<float*>(lds + free_stage * STAGE_H) + (threadIdx.x >> 6) * 1600;
-        int elane = threadIdx.x & 63;
+        float* wreg = reinterpret_cast<float*>(lds + free_stage * STAGE_H) + wave * (EROWS * 100);
+        int elane = pope_lane_id();
         asm volatile("" : "+v"(elane));
-        const int epiece = elane & 7;
         RL_STAMP(1);
         // The lane coordinates are re-derived behind an opaque fence: every address below would otherwise be hoisted
         // out of the tile loop as a loop invariant (~40 registers held across the K-steps: spills in the mainloop).
-        int l15 = threadIdx.x & 15, q4 = (threadIdx.x >> 4) & 3;
+        int l15 = elane & 15, q4 = elane >> 4;
         asm volatile("" : "+v"(l15), "+v"(q4));
+        const int er = l15 & (EROWS - 1);        // this lane's row of the transposition buffer
         // pin everything below behind the tile-end branch
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi)
@@ -186,19 +220,23 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
             const f32x4 bia = *reinterpret_cast<const f32x4*>(ctab + RN + col0 + 16 * ni);
 #pragma unroll
             for (int mi = 0; mi < NMI; ++mi) {
-                const unsigned row = unsigned(m0 + wm * 64 + mi * 16 + l15);
+                const unsigned row = unsigned(m0 + wm * WMR + mi * 16 + l15);
                 const unsigned rr = RES_TABLE ? row % unsigned(g.res_mod) : row;   // rows >= M: out of range -> 0
                 const f32x4 r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                     rres, rr * unsigned(g.ldres) * 4u + unsigned(col0) * 4u, ni * 64, 0));
                 acc[mi][ni] = r + acc[mi][ni] * gam + bia;
             }
+            // x is formed HERE: without the pin the middle end sinks the arithmetic of the later row blocks into the branches
+            // of phase 2 and keeps the loaded residual rows alive until then (spilled, each behind a vmcnt(0))
+#pragma unroll
+            for (int mi = 0; mi < NMI; ++mi) asm volatile("" : "+v"(acc[mi][ni]));
             __builtin_amdgcn_sched_barrier(0);   // one column block's residual rows in flight (2, 3 or 6: no difference —
                                                  // the phase runs at the memory system's speed, all CUs at once)
         }
         __builtin_amdgcn_sched_barrier(0);
         RL_STAMP(2);
         // ---- 2. row means: lane -> quad of lanes -> the four column waves (LDS) ------------------------------------
-        const int rl = wm * 64 + l15;   // row within the tile, + 16 mi
+        const int rl = wm * WMR + l15;   // row within the tile, + 16 mi
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) {
             float s = 0.f;
@@ -207,7 +245,7 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
             s = quad_sum(s);
             if (q4 == 0) stats[wn * RM + rl + 16 * mi] = s;
         }
-        __syncthreads();
+        rl_barrier();
         float mean[NMI], rstd[NMI];
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) {
@@ -216,20 +254,35 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
         }
         __builtin_amdgcn_sched_barrier(0);
         RL_STAMP(3);
+        // a pass of the transposition buffer: EROWS rows x 3 lines of 128 bytes, 8 lines per wave-instruction
+        auto store_lines = [&](const __amdgpu_buffer_rsrc_t& rdst, int row_base) {
+            // (coordinates re-derived per pass: hoisted, the x pass and the xn pass share 64-bit address pairs that the
+            // allocator spills and reloads behind vmcnt(0), i.e. behind every store in flight)
+            int el = elane;
+            asm volatile("" : "+v"(el));
+            const int epiece = el & 7;
+#pragma unroll
+            for (int t = 0; t < (EROWS * 3) / 8; ++t) {
+                const int L = t * 8 + (el >> 3), row = (L * 43) >> 7, ln = L - 3 * row;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&wreg[row * 100 + ln * 32 + epiece * 4]);
+                // planes rows and fp32 rows have the same pitch, and the wave's 96 columns are 384 bytes of either
+                const unsigned off = unsigned(row_base + row) * unsigned(RN) * 4u + unsigned(wn * 96 + ln * 32 + epiece * 4) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rdst, off, 0, 0);
+            }
+        };
         // ---- 3. x to memory (the residual stream), then centre in place and take the second moment -----------------
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) {
 #pragma unroll
-            for (int ni = 0; ni < 6; ++ni) *reinterpret_cast<f32x4*>(&wreg[l15 * 100 + ni * 16 + 4 * q4]) = acc[mi][ni];
-            __builtin_amdgcn_wave_barrier();
+            for (int h = 0; h < 16 / EROWS; ++h) {
+                if (EROWS == 16 || (l15 >> 3) == h) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {   // 48 lines of 128 bytes: 16 rows x 3
-                const int L = t * 8 + (elane >> 3), row = (L * 43) >> 7, ln = L - 3 * row;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&wreg[row * 100 + ln * 32 + epiece * 4]);
-                const unsigned off = unsigned(m0 + wm * 64 + mi * 16 + row) * unsigned(RN) * 4u + unsigned(wn * 96 + ln * 32 + epiece * 4) * 4u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rx, off, 0, 0);
+                    for (int ni = 0; ni < 6; ++ni) *reinterpret_cast<f32x4*>(&wreg[er * 100 + ni * 16 + 4 * q4]) = acc[mi][ni];
+                }
+                __builtin_amdgcn_wave_barrier();
+                store_lines(rx, m0 + wm * WMR + mi * 16 + h * EROWS);
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) {
@@ -243,7 +296,7 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
             qs = quad_sum(qs);
             if (q4 == 0) stats[4 * RM + wn * RM + rl + 16 * mi] = qs;
         }
-        __syncthreads();
+        rl_barrier();
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) {
             const float* p = stats + 4 * RM + rl + 16 * mi;
@@ -260,33 +313,31 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
 #pragma unroll
         for (int mi = 0; mi < NMI; ++mi) {
 #pragma unroll
-            for (int ni = 0; ni < 6; ++ni) {
-                const f32x4 lw = *reinterpret_cast<const f32x4*>(ctab + 2 * RN + col0 + 16 * ni);
-                const f32x4 lb = *reinterpret_cast<const f32x4*>(ctab + 3 * RN + col0 + 16 * ni);
-                const f32x4 y = acc[mi][ni] * rstd[mi] * lw + lb;
-                if constexpr (LN_PLANES) {
-                    const f32x4 ys = y * A_SCALE;
-                    pope_amax4x2(amax, ys);
-                    f16x4 hi, lo;
-                    pope_split4(ys, hi, lo);
-                    const int c = ni * 16 + 4 * q4;   // column within the wave's 96 = three planes chunks of 128 bytes
-                    _Float16* hp = reinterpret_cast<_Float16*>(wreg) + l15 * 200 + (c >> 5) * 64 + (c & 31);
-                    *reinterpret_cast<f16x4*>(hp) = hi;
-                    *reinterpret_cast<f16x4*>(hp + 32) = lo;
-                } else {
-                    *reinterpret_cast<f32x4*>(&wreg[l15 * 100 + ni * 16 + 4 * q4]) = y;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
+            for (int h = 0; h < 16 / EROWS; ++h) {
+                if (EROWS == 16 || (l15 >> 3) == h) {   // (8-row passes: a lane's quads go out in ONE of the two)
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const int L = t * 8 + (elane >> 3), row = (L * 43) >> 7, ln = L - 3 * row;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&wreg[row * 100 + ln * 32 + epiece * 4]);
-                // planes rows and fp32 rows have the same pitch, and the wave's 96 columns are 384 bytes of either
-                const unsigned off = unsigned(m0 + wm * 64 + mi * 16 + row) * unsigned(RN) * 4u + unsigned(wn * 96 + ln * 32 + epiece * 4) * 4u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rln, off, 0, 0);
+                    for (int ni = 0; ni < 6; ++ni) {
+                        const f32x4 lw = *reinterpret_cast<const f32x4*>(ctab + 2 * RN + col0 + 16 * ni);
+                        const f32x4 lb = *reinterpret_cast<const f32x4*>(ctab + 3 * RN + col0 + 16 * ni);
+                        const f32x4 y = acc[mi][ni] * rstd[mi] * lw + lb;
+                        if constexpr (LN_PLANES) {
+                            const f32x4 ys = y * A_SCALE;
+                            pope_amax4x2(amax, ys);
+                            f16x4 hi, lo;
+                            pope_split4(ys, hi, lo);
+                            const int c = ni * 16 + 4 * q4;   // column within the wave's 96 = three planes chunks of 128 bytes
+                            _Float16* hp = reinterpret_cast<_Float16*>(wreg) + er * 200 + (c >> 5) * 64 + (c & 31);
+                            *reinterpret_cast<f16x4*>(hp) = hi;
+                            *reinterpret_cast<f16x4*>(hp + 32) = lo;
+                        } else {
+                            *reinterpret_cast<f32x4*>(&wreg[er * 100 + ni * 16 + 4 * q4]) = y;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                store_lines(rln, m0 + wm * WMR + mi * 16 + h * EROWS);
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
         if constexpr (LN_PLANES)   // a non-finite row (poisoned x) has a non-finite mean or rstd; fmax ignores NaN
             pope_range_flag(g.range_flag, POPE_RANGE_LAYERNORM,
@@ -295,31 +346,42 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
         RL_STAMP(5);
     };
 
-    // prologue: item 0 -> LDS stage 0; item 1 in flight
-    load_next();
-    write_stage(0);
-    load_next();
-    __syncthreads();
+    // prologue: the first K-step of the first tile -> stage 0
+    dma(0, first, 0);
     zero_acc();
-    int tile = first, kt = 0;
+    int tile = first, kt = 0, ord = 0, next_tile = tile_of(1);
     RL_STAMP(0);
 
-    auto item = [&](int s) {
+    for (int s = 0; tile < n_tiles; ++s) {
+        // This wave's pieces of stage s have landed.  After a tile seam nothing is waited for: the step's loads were issued
+        // before the epilogue, whose residual loads — younger, and returning in order — have been consumed since; waiting here
+        // would wait for the acknowledgement of the epilogue's last stores.
+        if (kt != 0 || ord == 0) __builtin_amdgcn_s_waitcnt(0x0f70);
+        rl_barrier();   // ... and everyone's; every wave has left the other stage (K-step s - 1, or the epilogue's buffers)
+        const bool seam = kt + 1 == nk;
+        dma((s + 1) & 1, seam ? next_tile : tile, seam ? 0 : kt + 1);
         const _Float16* S = lds + (s & 1) * STAGE_H;
+        // fragment t: rows 16 t + l15 of this wave's rows, logical chunk plane * 4 + q4
+        int fl_ = pope_lane_id();
+        asm volatile("" : "+v"(fl_));
+        const int fl15 = fl_ & 15, fq4 = fl_ >> 4;
+        const int sw_hi = 8 * (fq4 ^ (fl15 & 7)), sw_lo = 8 * ((4 + fq4) ^ (fl15 & 7));
+        const int a_row = (wm * WMR + fl15) * ROWB, w_row = (RM + wn * 96 + fl15) * ROWB;
         // ni-major: the A fragments (hi, lo: 8 x 4 registers) stay for the K-step, the W fragments stream through two at
-        // a time (lo, hi of column block ni), each feeding 12 MFMAs — 48 fragment registers instead of 80 (the kernel
-        // sits at the 256-register line: 96 accumulators + 32 staging).  Per accumulator the order of the partial
+        // a time (lo, hi of column block ni), each feeding 12 MFMAs.  Per accumulator the order of the partial
         // products is that of gemm_planes.hip (lo.hi, hi.lo, hi.hi): bit-identical sums.
         // Program order is pinned with scheduling fences: the scheduler otherwise hoists all 20 fragment reads to the
-        // top of the K-step (80 live registers) and spills the in-flight staging registers to scratch.
+        // top of the K-step (80 live registers).
         f16x8 ah[NMI], al[NMI], wl[2], wh[2];
-#pragma unroll
-        for (int t = 0; t < NMI; ++t) {
-            ah[t] = *reinterpret_cast<const f16x8*>(S + a_row + t * 16 * ROWB + sw_hi);
-            al[t] = *reinterpret_cast<const f16x8*>(S + a_row + t * 16 * ROWB + sw_lo);
-        }
+        // issue order = order of first use (the LDS returns in order): the first MFMA (wl[0] . ah[0]) waits for two reads, every
+        // further one of the first column block for one more — not for the whole 2 NMI + 2 (the waves of the workgroup all read at
+        // this point: 14 reads x 8 waves are 900 cycles of the LDS array)
         wl[0] = *reinterpret_cast<const f16x8*>(S + w_row + sw_lo);
+#pragma unroll
+        for (int t = 0; t < NMI; ++t) ah[t] = *reinterpret_cast<const f16x8*>(S + a_row + t * 16 * ROWB + sw_hi);
         wh[0] = *reinterpret_cast<const f16x8*>(S + w_row + sw_hi);
+#pragma unroll
+        for (int t = 0; t < NMI; ++t) al[t] = *reinterpret_cast<const f16x8*>(S + a_row + t * 16 * ROWB + sw_lo);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ni = 0; ni < 6; ++ni) {
@@ -328,14 +390,8 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
                 wl[nxt] = *reinterpret_cast<const f16x8*>(S + w_row + (ni + 1) * 16 * ROWB + sw_lo);
                 wh[nxt] = *reinterpret_cast<const f16x8*>(S + w_row + (ni + 1) * 16 * ROWB + sw_hi);
             }
-            // item s+1 goes to LDS late in the K-step and item s+2 is requested right after it: the staging registers
-            // are loaded for almost a whole K-step — except across a tile seam: the epilogue needs those registers (with
-            // them live it spills, and a spill reload drains vmcnt, i.e. waits for every load in flight), so the seam
-            // load is issued after the epilogue and still has four column groups of MFMAs to arrive
-            if (ni == 4) write_stage((s + 1) & 1);
-            if (ni == 5 && kt + 1 != nk) load_next();
             if constexpr (!RES_TABLE)
-                if (ni == 2 && g.rl_prefetch && pf_step > 0 && kt % pf_step == 0 && kt / pf_step < 3) prefetch_res(tile, kt / pf_step);
+                if (ni == 2 && g.rl_prefetch && pf_step > 0 && kt % pf_step == 0 && kt / pf_step < G::NPF) prefetch_res(tile, kt / pf_step);
 #pragma unroll
             for (int mi = 0; mi < NMI; ++mi) acc[mi][ni] = mfma16(wl[cur], ah[mi], acc[mi][ni]);
 #pragma unroll
@@ -344,28 +400,40 @@ __global__ __launch_bounds__(RTH, 2) void gemm_rowln16_kernel(const GemmParams g
             for (int mi = 0; mi < NMI; ++mi) acc[mi][ni] = mfma16(wh[cur], ah[mi], acc[mi][ni]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();  // stage (s+1)&1 is published, stage s&1 is free
         if (++kt == nk) {
+            rl_barrier();   // every wave has finished reading stage s & 1: it holds the transposition buffers now
             epilogue(tile, s & 1);
-            __syncthreads();   // the next K-step stores into the stage the slower waves may still be transposing through
-            load_next();   // the K-step after the one already in LDS
             zero_acc();
             kt = 0;
-            tile = tile_of(++ord);
+            tile = next_tile;
+            next_tile = tile_of(++ord + 1);
             rl_si += 8;
             RL_STAMP(0);
         }
-    };
-    for (int s = 0; tile < n_tiles; ++s) item(s);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // the last (re-)load into LDS has landed before the workgroup gives the LDS back
 }
 
+template <class G, bool LN_PLANES, bool RES_TABLE>
+int launch_rowln_geo(const GemmParams& g, hipStream_t stream) {
+    static pope_dev_mask lds_ok{0};   // per kernel instantiation, per device
+    if (!pope_opt_in_lds(gemm_rowln16_kernel<G, LN_PLANES, RES_TABLE>, G::LDS_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
+    const int tiles = (g.M + G::RM - 1) / G::RM, cus = pope_cu_count();
+    hipLaunchKernelGGL((gemm_rowln16_kernel<G, LN_PLANES, RES_TABLE>), dim3(tiles < cus ? tiles : cus), dim3(G::RTH), G::LDS_BYTES, stream,
+                       g, tiles);
+    return pope_check_launch();
+}
+
+// Two tile geometries, the same arithmetic (bit-identical results): 192 rows (2 x 4 waves of 96 x 96: 1.0 staged byte per output
+// and K-step) where its rounds over the CUs cost no more row-rounds than the 128-row tile's (2 x 4 waves of 64 x 96: 1.33 bytes),
+// e.g. the 64-image chunk: 511 tiles = 2 rounds x 192 against 766 tiles = 3 rounds x 128; mid-size batches that fill less than a
+// round of 192-row tiles keep the smaller tile.
 template <bool LN_PLANES, bool RES_TABLE>
 int launch_rowln(const GemmParams& g, hipStream_t stream) {
-    static pope_dev_mask lds_ok{0};
-    if (!pope_opt_in_lds(gemm_rowln16_kernel<LN_PLANES, RES_TABLE>, RL_LDS_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
-    const int tiles = (g.M + RM - 1) / RM, cus = pope_cu_count();
-    hipLaunchKernelGGL((gemm_rowln16_kernel<LN_PLANES, RES_TABLE>), dim3(tiles < cus ? tiles : cus), dim3(RTH), RL_LDS_BYTES, stream, g, tiles);
-    return pope_check_launch();
+    const long long cus = pope_cu_count();
+    const long long r128 = ((g.M + 127) / 128 + cus - 1) / cus * 128, r192 = ((g.M + 191) / 192 + cus - 1) / cus * 192;
+    return r192 <= r128 ? launch_rowln_geo<RlGeo<192, 2>, LN_PLANES, RES_TABLE>(g, stream)
+                        : launch_rowln_geo<RlGeo<128, 2>, LN_PLANES, RES_TABLE>(g, stream);
 }
 
 }  // namespace
@@ -378,7 +446,7 @@ extern "C" int pope_lab_rowln_stamps(unsigned long long* host192) {
 
 bool pope_gemm_rowln_supported(const GemmParams& g) {
     return g.N == RN && g.ldc == RN && g.K >= 2 * RK && (g.K % RK) == 0 && g.lda == g.K && g.ldw == g.K && g.ldres == RN &&
-           size_t(g.M + RM) * g.lda * 4 < (size_t(1) << 32) && size_t(g.M + RM) * RN * 4 < (size_t(1) << 32) - 512;
+           size_t(g.M + 192) * g.lda * 4 < (size_t(1) << 32) && size_t(g.M + 192) * RN * 4 < (size_t(1) << 32) - 512;
 }
 
 // x = res + gamma * (A.W^T + bias) -> g.C (fp32, may alias res), LayerNorm(x; ln_w, ln_b, ln_eps) -> g.ln_planes or g.ln_f32

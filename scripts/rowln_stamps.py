@@ -9,7 +9,7 @@ model = load_dinov2_model(state_dict=synth.synthetic_state_dict(seed=0)).to(dev)
 x = synth.synthetic_images(64, 476, 630, seed=1).to(dev)
 for _ in range(3): model(x)
 torch.cuda.synchronize()
-lib = C.CDLL(_lib.LIB_PATH)
+lib = C.CDLL(_lib.LIB_PATH)  # the handle the model already uses
 buf = (C.c_ulonglong * 192)()
 assert lib.pope_lab_rowln_stamps(buf) == 0
 names = ["K loop", "residual + x (phase 1)", "row means (2)", "store x + 2nd moment (3)", "LN + planes stores (4)", "seam: next K-step load + first item"]

@@ -48,6 +48,24 @@ def test_vit_chunk_of_64_at_476x630(model, dev, golden_dir):
     assert model.overflow_events == 0
 
 
+def test_fused_layernorm_gemm_tile_geometries_agree(dev, sd0):
+    """gemm_rowln.hip serves a 64-image chunk with 192-row tiles (511 tiles = 2 rounds of the CUs) and a 20-image batch
+    (30 620 rows: less than a round of either) with 128-row tiles; below 21 760 rows the GEMM + LayerNorm twin runs.
+    Images are independent in the reference, so the three routes must return the same bits for the same image."""
+    from pope_amd import synth
+    from pope_amd.dinov2_utils import load_dinov2_model
+    m = load_dinov2_model(state_dict=sd0).to(dev)
+    x = synth.synthetic_images(64, H, W, seed=5).to(dev)
+    big = m(x, is_training=True)
+    mid = m(x[:20], is_training=True)
+    for key in ("x_norm_patchtokens", "x_norm_clstoken", "x_prenorm"):
+        assert torch.equal(mid[key], big[key][:20]), key
+    one = m(x[19:20], is_training=True)
+    assert torch.equal(one["x_norm_patchtokens"][0], mid["x_norm_patchtokens"][19])
+    assert torch.equal(one["x_prenorm"][0], mid["x_prenorm"][19])
+    assert m.overflow_events == 0
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
 def test_dense_match_128_pairs_at_1530(dev, sd0, golden_dir, precision):
     from pope_amd import synth
