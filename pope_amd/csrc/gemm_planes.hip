@@ -573,6 +573,10 @@ int pope_launch_planes16(const GemmParams& g, hipStream_t stream) {
     }
     // planes -> planes at large M (QKV, FC1 of the ViT blocks): the 256 x 256 LDS-direct mainloop of gemm_plain.hip, same bits
     // (round 4, same-box A/B inside bench.py: QKV 0.285 -> 0.273 ms, FC1 0.427 -> 0.351 ms, step 92.9 -> 89.0 ms)
+    // large planes -> planes Linears on the LDS-direct mainloops (bit-identical to the tile kernel below): widths that leave a
+    // partial 256-column tile but are multiples of 384 (QKV 1 152: 4.5 tiles of 256) on the 192 x 384 stream of gemm_rowln.hip
+    // (0.294 -> 0.266 ms; FC1's 1 536 = 6 x 256 is 2 % faster on the 256 x 256 tiles: profiles/r04/stream384_ab.txt)
+    if ((g.N & 255) && pope_stream384_supported(g)) return pope_launch_stream384(g, stream);
     if (pope_wide_x3_supported(g)) return pope_launch_wide_x3(g, stream);
     switch (g.epilogue) {
         case EPI_BIAS: return out_planes ? launch16<EPI_BIAS, true>(g, stream) : launch16<EPI_BIAS, false>(g, stream);

@@ -98,8 +98,38 @@ __device__ __forceinline__ void rl_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <class G, bool LN_PLANES, bool RES_TABLE>
-__global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g, int n_tiles) {
+// MODE: what leaves the tile.  RL_LN_PLANES / RL_LN_F32: x (fp32) and LayerNorm(x) as activation planes / fp32 — ONE column
+// tile (N = 384); RL_BIAS_PLANES / RL_GELU_PLANES (round 4): A.W^T + bias (+ exact-erf GELU) as activation planes, any number
+// of 384-column tiles (QKV: 3, FC1: 4 — the ViT-S/14 widths are multiples of 384, so the 192 x 384 stream has no partial
+// column tile, where 256 x 256 tiles compute 1 280 columns for QKV's 1 152), in gemm_plain.hip's epilogue arithmetic.
+enum { RL_LN_PLANES = 0, RL_LN_F32 = 1, RL_BIAS_PLANES = 2, RL_GELU_PLANES = 3 };
+
+// exact-erf GELU on a pair: the arithmetic of gemm_planes.hip:gelu_erf_pair, instruction for instruction (bit-identical)
+__device__ __forceinline__ f32x2 rl_gelu_pair(f32x2 x) {
+    constexpr float P = 0.3275911f * 0.70710678118654752440f;
+    constexpr float A1 = 0.5f * 0.254829592f, A2 = 0.5f * -0.284496736f, A3 = 0.5f * 1.421413741f,
+                    A4 = 0.5f * -1.453152027f, A5 = 0.5f * 1.061405429f;
+    constexpr float NHL2E = -0.5f * 1.44269504088896340736f;
+    f32x2 t, e, relu;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        t[i] = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x[i]), P, 1.0f));
+        relu[i] = __builtin_fmaxf(x[i], 0.0f);
+    }
+    const f32x2 arg = (x * NHL2E) * x;
+    e[0] = __builtin_amdgcn_exp2f(arg[0]);
+    e[1] = __builtin_amdgcn_exp2f(arg[1]);
+    f32x2 poly = __builtin_elementwise_fma(t, f32x2{A5, A5}, f32x2{A4, A4});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{A3, A3});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{A2, A2});
+    poly = __builtin_elementwise_fma(poly, t, f32x2{A1, A1});
+    const f32x2 q = (poly * t) * e;
+    return __builtin_elementwise_fma(relu, __builtin_elementwise_fma(q, f32x2{-2.f, -2.f}, f32x2{1.f, 1.f}), x * q);
+}
+
+template <class G, int MODE, bool RES_TABLE>
+__global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g, int n_tiles, int ncol) {
+    constexpr bool LN = MODE == RL_LN_PLANES || MODE == RL_LN_F32, LN_PLANES = MODE == RL_LN_PLANES;
     constexpr int RM = G::RM, NMI = G::NMI, RTH = G::RTH, STAGE_H = G::STAGE_H, EROWS = G::EROWS, AROWS = G::AROWS, WROWS = G::WROWS;
     constexpr int WMR = 16 * NMI;                      // rows of a wave
     constexpr int NIA = AROWS / 8, NIW = WROWS / 8;    // staging instructions per wave and K-step
@@ -116,7 +146,10 @@ __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g
     const int nk = g.K / RK;  // >= 2 (launcher)
     const unsigned lda4 = unsigned(g.lda) * 4u, ldw4 = unsigned(g.ldw) * 4u;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, unsigned(g.M) * lda4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, unsigned(RN) * ldw4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, unsigned(g.N) * ldw4, 0x00020000);
+    // tile id -> (row tile, column tile): the column tiles of a row tile are neighbours in the stream (the A rows leave HBM once)
+    auto row_tile = [&](int t) -> int { return LN ? t : t / ncol; };
+    auto col_tile = [&](int t) -> int { return LN ? 0 : t - (t / ncol) * ncol; };
 
     // tile stream: full rounds by XCD-remapped id, the partial last round by raw blockIdx (gemm_planes.hip)
     const int grid = gridDim.x, full_rounds = n_tiles / grid;
@@ -129,7 +162,7 @@ __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g
     };
     const int first = tile_of(0);
     if (first >= n_tiles) return;
-    if (tid < RN) {
+    if (LN && tid < RN) {
         const float gm = g.gamma ? g.gamma[tid] : 1.0f;
         ctab[tid] = gm * (1.0f / (A_SCALE * W_SCALE));   // res + (v/scale + bias)*gamma = res + v*(gamma/scale) + bias*gamma
         ctab[RN + tid] = (g.bias ? g.bias[tid] : 0.f) * gm;
@@ -154,11 +187,12 @@ __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g
         const int r8 = ln_ >> 3, piece = (ln_ & 7) ^ r8;
         const int lt = t < n_tiles ? t : n_tiles - 1;   // past the end: re-load, never consumed
         _Float16* S_ = lds + stage * STAGE_H;
-        const unsigned vt = unsigned(lt * RM + AROWS * wave + r8) * lda4 + unsigned(piece) * 16u, ko = unsigned(kt_) * 128u;
+        const unsigned vt = unsigned(row_tile(lt) * RM + AROWS * wave + r8) * lda4 + unsigned(piece) * 16u;
+        const unsigned ko = unsigned(kt_) * 128u + unsigned(col_tile(lt)) * unsigned(RN) * ldw4;   // (zero column offset for the A loads below: LN)
         const unsigned vw0 = unsigned(WROWS * wave + r8) * ldw4 + unsigned(piece) * 16u;
 #pragma unroll
         for (int i = 0; i < NIA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(S_ + (AROWS * wave + 8 * i) * ROWB), 16, vt + i * a8, ko, 0, 3);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(S_ + (AROWS * wave + 8 * i) * ROWB), 16, vt + i * a8, unsigned(kt_) * 128u, 0, LN ? 3 : 0);
 #pragma unroll
         for (int i = 0; i < NIW; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_ptr)(S_ + (RM + WROWS * wave + 8 * i) * ROWB), 16, vw0, ko + i * w8, 0, 0);
@@ -171,6 +205,7 @@ __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g
             for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
+    // (LN modes; in the planes modes these descriptors are never used)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, unsigned(g.M) * unsigned(RN) * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rln = __builtin_amdgcn_make_buffer_rsrc(LN_PLANES ? g.ln_planes : static_cast<void*>(g.ln_f32), 0,
                                                                          unsigned(g.M) * unsigned(RN) * 4u, 0x00020000);
@@ -193,7 +228,7 @@ __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g
     };
 
     int rl_si = 0;   // stamp index (dev builds)
-    auto epilogue = [&](int tile, int free_stage) {
+    [[maybe_unused]] auto epilogue = [&](int tile, int free_stage) {
         const int m0 = tile * RM;
         // per-wave transposition buffer in the LDS stage the K loop has just finished with (the other stage is receiving
         // the next tile's first K-step): EROWS rows x 96 columns of this wave at a time, 400-byte pitch (conflict-free
@@ -346,6 +381,69 @@ __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g
         RL_STAMP(5);
     };
 
+    // ---- planes epilogue (RL_BIAS_PLANES / RL_GELU_PLANES): y = acc / scale + bias [-> GELU] -> activation planes, through the
+    // same per-wave transposition buffer and whole-line stores; the arithmetic is gemm_plain.hip's (bit-identical outputs)
+    const __amdgpu_buffer_rsrc_t rcp = __builtin_amdgcn_make_buffer_rsrc(LN ? static_cast<void*>(g.C) : g.c_pl, 0,
+                                                                         unsigned(g.M) * unsigned(g.ldc) * 4u, 0x00020000);
+    [[maybe_unused]] auto epilogue_planes = [&](int tile, int free_stage) {
+        const int m0 = row_tile(tile) * RM, n0 = col_tile(tile) * RN;
+        float* wreg = reinterpret_cast<float*>(lds + free_stage * STAGE_H) + wave * (EROWS * 100);
+        int elane = pope_lane_id();
+        asm volatile("" : "+v"(elane));
+        int l15 = elane & 15, q4 = elane >> 4;
+        asm volatile("" : "+v"(l15), "+v"(q4));
+        const int er = l15 & (EROWS - 1);
+#pragma unroll
+        for (int mi = 0; mi < NMI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 6; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
+        const int col0 = n0 + wn * 96 + 4 * q4;   // this lane's columns: col0 + 16 ni .. + 3
+        constexpr float inv = 1.0f / (A_SCALE * W_SCALE);
+        f32x4 bias[6];   // loaded before the first store of the epilogue (a load between stores waits for every store in flight)
+#pragma unroll
+        for (int ni = 0; ni < 6; ++ni) bias[ni] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + col0 + 16 * ni) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x2 amax = {0.f, 0.f};
+#pragma unroll
+        for (int mi = 0; mi < NMI; ++mi) {
+#pragma unroll
+            for (int h = 0; h < 16 / EROWS; ++h) {
+                if (EROWS == 16 || (l15 >> 3) == h) {
+#pragma unroll
+                    for (int ni = 0; ni < 6; ++ni) {
+                        f32x4 v = acc[mi][ni] * inv + bias[ni];
+                        if constexpr (MODE == RL_GELU_PLANES) {
+                            const f32x2 g01 = rl_gelu_pair(f32x2{v[0], v[1]}), g23 = rl_gelu_pair(f32x2{v[2], v[3]});
+                            v = f32x4{g01[0], g01[1], g23[0], g23[1]};
+                        }
+                        pope_amax4x2(amax, v);
+                        f16x4 hi, lo;
+                        pope_split4(v * A_SCALE, hi, lo);
+                        const int c = ni * 16 + 4 * q4;   // column within the wave's 96 = three planes chunks of 128 bytes
+                        _Float16* hp = reinterpret_cast<_Float16*>(wreg) + er * 200 + (c >> 5) * 64 + (c & 31);
+                        *reinterpret_cast<f16x4*>(hp) = hi;
+                        *reinterpret_cast<f16x4*>(hp + 32) = lo;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                {   // EROWS rows x 3 lines of 128 bytes, 8 lines per wave-instruction (write-once output: non-temporal)
+                    int el = elane;
+                    asm volatile("" : "+v"(el));
+                    const int epiece = el & 7;
+                    const int row_base = m0 + wm * WMR + mi * 16 + h * EROWS;
+#pragma unroll
+                    for (int t = 0; t < (EROWS * 3) / 8; ++t) {
+                        const int L = t * 8 + (el >> 3), row = (L * 43) >> 7, ln = L - 3 * row;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(&wreg[row * 100 + ln * 32 + epiece * 4]);
+                        const unsigned off = unsigned(row_base + row) * unsigned(g.ldc) * 4u + unsigned(n0 + wn * 96 + ln * 32 + epiece * 4) * 4u;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rcp, off, 0, 2);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        pope_range_flag(g.range_flag, g.range_bit, !(__builtin_fmaxf(amax[0], amax[1]) * A_SCALE < POPE_F16_OVERFLOW));
+    };
+
     // prologue: the first K-step of the first tile -> stage 0
     dma(0, first, 0);
     zero_acc();
@@ -390,7 +488,7 @@ __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g
                 wl[nxt] = *reinterpret_cast<const f16x8*>(S + w_row + (ni + 1) * 16 * ROWB + sw_lo);
                 wh[nxt] = *reinterpret_cast<const f16x8*>(S + w_row + (ni + 1) * 16 * ROWB + sw_hi);
             }
-            if constexpr (!RES_TABLE)
+            if constexpr (LN && !RES_TABLE)
                 if (ni == 2 && g.rl_prefetch && pf_step > 0 && kt % pf_step == 0 && kt / pf_step < G::NPF) prefetch_res(tile, kt / pf_step);
 #pragma unroll
             for (int mi = 0; mi < NMI; ++mi) acc[mi][ni] = mfma16(wl[cur], ah[mi], acc[mi][ni]);
@@ -402,7 +500,8 @@ __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g
         }
         if (++kt == nk) {
             rl_barrier();   // every wave has finished reading stage s & 1: it holds the transposition buffers now
-            epilogue(tile, s & 1);
+            if constexpr (LN) epilogue(tile, s & 1);
+            else epilogue_planes(tile, s & 1);
             zero_acc();
             kt = 0;
             tile = next_tile;
@@ -414,13 +513,14 @@ __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g
     __builtin_amdgcn_s_waitcnt(0x0f70);   // the last (re-)load into LDS has landed before the workgroup gives the LDS back
 }
 
-template <class G, bool LN_PLANES, bool RES_TABLE>
+template <class G, int MODE, bool RES_TABLE>
 int launch_rowln_geo(const GemmParams& g, hipStream_t stream) {
     static pope_dev_mask lds_ok{0};   // per kernel instantiation, per device
-    if (!pope_opt_in_lds(gemm_rowln16_kernel<G, LN_PLANES, RES_TABLE>, G::LDS_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
-    const int tiles = (g.M + G::RM - 1) / G::RM, cus = pope_cu_count();
-    hipLaunchKernelGGL((gemm_rowln16_kernel<G, LN_PLANES, RES_TABLE>), dim3(tiles < cus ? tiles : cus), dim3(G::RTH), G::LDS_BYTES, stream,
-                       g, tiles);
+    if (!pope_opt_in_lds(gemm_rowln16_kernel<G, MODE, RES_TABLE>, G::LDS_BYTES, lds_ok)) return POPE_ERR_LAUNCH;
+    const int ncol = (g.N + RN - 1) / RN;
+    const int tiles = ((g.M + G::RM - 1) / G::RM) * ncol, cus = pope_cu_count();
+    hipLaunchKernelGGL((gemm_rowln16_kernel<G, MODE, RES_TABLE>), dim3(tiles < cus ? tiles : cus), dim3(G::RTH), G::LDS_BYTES, stream,
+                       g, tiles, ncol);
     return pope_check_launch();
 }
 
@@ -428,12 +528,12 @@ int launch_rowln_geo(const GemmParams& g, hipStream_t stream) {
 // and K-step) where its rounds over the CUs cost no more row-rounds than the 128-row tile's (2 x 4 waves of 64 x 96: 1.33 bytes),
 // e.g. the 64-image chunk: 511 tiles = 2 rounds x 192 against 766 tiles = 3 rounds x 128; mid-size batches that fill less than a
 // round of 192-row tiles keep the smaller tile.
-template <bool LN_PLANES, bool RES_TABLE>
+template <int MODE, bool RES_TABLE>
 int launch_rowln(const GemmParams& g, hipStream_t stream) {
-    const long long cus = pope_cu_count();
-    const long long r128 = ((g.M + 127) / 128 + cus - 1) / cus * 128, r192 = ((g.M + 191) / 192 + cus - 1) / cus * 192;
-    return r192 <= r128 ? launch_rowln_geo<RlGeo<192, 2>, LN_PLANES, RES_TABLE>(g, stream)
-                        : launch_rowln_geo<RlGeo<128, 2>, LN_PLANES, RES_TABLE>(g, stream);
+    const long long cus = pope_cu_count(), ncol = (g.N + RN - 1) / RN;
+    const long long r128 = (((g.M + 127) / 128) * ncol + cus - 1) / cus * 128, r192 = (((g.M + 191) / 192) * ncol + cus - 1) / cus * 192;
+    return r192 <= r128 ? launch_rowln_geo<RlGeo<192, 2>, MODE, RES_TABLE>(g, stream)
+                        : launch_rowln_geo<RlGeo<128, 2>, MODE, RES_TABLE>(g, stream);
 }
 
 }  // namespace
@@ -456,6 +556,25 @@ int pope_launch_gemm_rowln(const GemmParams& g_in, hipStream_t stream) {
     if (!g.a_pl || !g.w_pl || !g.C || !g.res || !g.ln_w || !g.ln_b || (!g.ln_planes) == (!g.ln_f32) || g.M <= 0) return POPE_ERR_ARG;
     if (!pope_gemm_rowln_supported(g)) return POPE_ERR_ARG;
     if (g.res_mod < 0 || (g.res_mod == 0 && !g.gamma)) return POPE_ERR_ARG;
-    if (g.res_mod > 0) return g.ln_planes ? launch_rowln<true, true>(g, stream) : launch_rowln<false, true>(g, stream);
-    return g.ln_planes ? launch_rowln<true, false>(g, stream) : launch_rowln<false, false>(g, stream);
+    if (g.res_mod > 0) return g.ln_planes ? launch_rowln<RL_LN_PLANES, true>(g, stream) : launch_rowln<RL_LN_F32, true>(g, stream);
+    return g.ln_planes ? launch_rowln<RL_LN_PLANES, false>(g, stream) : launch_rowln<RL_LN_F32, false>(g, stream);
+}
+
+// planes -> planes Linear (BIAS, BIAS_GELU) on the same stream for widths that are multiples of 384 (ViT-S/14: QKV 1 152, FC1
+// 1 536) at batches of several rounds: no partial column tile, the next tile's first K-step lands under the epilogue
+bool pope_stream384_supported(const GemmParams& g) {
+    if (g.plain || !g.a_pl || !g.w_pl || !g.c_pl || g.conv_cch > 0 || g.nbatch > 1) return false;
+    if (g.epilogue != EPI_BIAS && g.epilogue != EPI_BIAS_GELU) return false;
+    if (g.N % RN || g.K < 2 * RK || (g.K % RK) || g.lda != g.K || g.ldw != g.K || g.ldc != g.N) return false;
+    if (size_t(g.M + 192) * g.lda * 4 >= (size_t(1) << 32) || size_t(g.N) * g.ldw * 4 >= (size_t(1) << 32) ||
+        size_t(g.M + 192) * g.ldc * 4 >= (size_t(1) << 32) - 512)
+        return false;
+    // several rounds of 192-row tiles: one workgroup per CU, nothing runs under a tile's K loop but its own staging
+    return size_t((g.M + 191) / 192) * (g.N / RN) >= size_t(4) * pope_cu_count();
+}
+
+int pope_launch_stream384(const GemmParams& g, hipStream_t stream) {
+    if (!pope_stream384_supported(g)) return POPE_ERR_ARG;
+    return g.epilogue == EPI_BIAS_GELU ? launch_rowln_geo<RlGeo<192, 2>, RL_GELU_PLANES, false>(g, stream)
+                                       : launch_rowln_geo<RlGeo<192, 2>, RL_BIAS_PLANES, false>(g, stream);
 }

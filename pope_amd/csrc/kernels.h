@@ -99,6 +99,9 @@ int pope_launch_sim_f16x3_planes(const GemmParams& g, hipStream_t stream);  // E
 // residual GEMM + the following LayerNorm in one kernel (gemm_rowln.hip; N = 384 only: `supported` says)
 bool pope_gemm_rowln_supported(const GemmParams& g);
 int pope_launch_gemm_rowln(const GemmParams& g, hipStream_t stream);
+// the same 192 x 384 LDS-direct tile stream for planes -> planes Linears whose width is a multiple of 384 (gemm_rowln.hip)
+bool pope_stream384_supported(const GemmParams& g);
+int pope_launch_stream384(const GemmParams& g, hipStream_t stream);
 // plain-f16 long-K mainloop (gemm_plain.hip: 256-row tiles, LDS-direct staging) for the GemmParams::plain shapes it serves;
 // same results as pope_launch_planes16 on them
 bool pope_wide_x3_supported(const GemmParams& g);   // the same mainloop on f16x3 planes -> planes (BIAS, BIAS_GELU) at large M

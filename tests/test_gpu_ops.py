@@ -327,16 +327,22 @@ def test_linear_planes_ragged_shapes(dev, hip_lib, shape):
     _close(guard[:M].cpu(), F.linear(a.double(), w.double(), b.double()).float(), atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("route", ["wide256", "stream384"])
 @pytest.mark.parametrize("N,epi", [(1152, 0), (1536, 1)])
-def test_wide_planes_gemm_equals_tile_kernel(dev, hip_lib, N, epi):
-    """Planes -> planes Linear layers at large M (QKV, FC1 . GELU of the ViT blocks) run on the 256 x 256 LDS-direct mainloop of
-    gemm_plain.hip (round 4); every other call on the 128 x 128 tile kernel.  Same accumulation order, same epilogue
-    arithmetic: the big call must equal, bit for bit, the same rows computed in pieces small enough to take the tile kernel —
-    with a ragged last row tile, and the range flag raised by the same outlier."""
+def test_wide_planes_gemm_equals_tile_kernel(dev, hip_lib, N, epi, route):
+    """Planes -> planes Linear layers at large M (QKV, FC1 . GELU of the ViT blocks) run on LDS-direct mainloops (round 4): from
+    4 x CUs tiles of 192 x 384 on the persistent tile stream of gemm_rowln.hip (widths that are multiples of 384), below that
+    from 4 x CUs tiles of 256 x 256 on gemm_plain.hip; every other call on the 128 x 128 tile kernel.  Same accumulation order,
+    same epilogue arithmetic: the big call must equal, bit for bit, the same rows computed in pieces small enough to take the
+    tile kernel — with a ragged last row tile, and the range flag raised by the same outlier."""
     import ctypes as C
     from pope_amd import _lib
     K = 384
-    M = 256 * (1024 // (-(-N // 256)) + 3) + 77          # a few more than 4 x CUs tiles of 256 x 256, ragged
+    if route == "wide256":
+        M = 256 * (1024 // (-(-N // 256)) + 3) + 77      # a few more than 4 x CUs tiles of 256 x 256, ragged; fewer than 4 x CUs of 192 x 384
+        assert -(-M // 192) * (N // 384) < 1024
+    else:
+        M = 192 * (1024 // (N // 384) + 3) + 77          # a few more than 4 x CUs tiles of 192 x 384, ragged
     g = torch.Generator().manual_seed(N)
     a = torch.randn(M, K, generator=g) * 1.3
     w, b = torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
