@@ -546,7 +546,7 @@ def roofline_entry(dominant, dom, peak_tflops, mfma_factor, chunk, pmc=True):
         "note": "algorithmic FLOPs / HIP-event duration of every launch of this kernel inside the timed "
                 "region (events on the launch stream); peak = dense MFMA peak of the MFMA dtype "
                 "(MI355X_MICROARCH.md); f16x3 executes 3 MFMA FLOPs per algorithmic FLOP; `traffic` = HBM bytes per "
-                "launch from the committed rocprofv3 --pmc pass (profiles/pmc_traffic.json <- profiles/r03/pmc_summary.txt), "
+                "launch from the committed rocprofv3 --pmc pass (profiles/pmc_traffic.json <- profiles/r04/pmc_summary.txt), "
                 "not measured in this run",
     }
 

@@ -1,12 +1,14 @@
 """profiles/pmc_traffic.json (the `roofline.traffic` figures bench.py reports) from a pmc_summary.txt written by
 scripts/profile_round.sh: HBM / fabric bytes per launch = FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE,
-both in KiB.  Usage: python scripts/pmc_traffic.py profiles/r03/pmc_summary.txt > profiles/pmc_traffic.json"""
+both in KiB.  Usage: python scripts/pmc_traffic.py profiles/r04/pmc_summary.txt > profiles/pmc_traffic.json"""
 import json
 import re
 import sys
 
-KERNELS = {"attention": "attn_f16x3_pipe_kernel<true, true, false>", "gemm_qkv": "gemm_planes16_kernel<0, true, false, false>",
-           "gemm_fc1_gelu": "gemm_planes16_kernel<1, true, false, false>", "gemm_proj": "gemm_rowln16_kernel<true, false>"}
+# round 4: QKV on the 192 x 384 tile stream (mode 2 = bias -> planes), FC1 on the 256 x 256 LDS-direct tiles, proj / FC2 on the stream's
+# LayerNorm-fused mode 0 (averaged over its proj and FC2 launches)
+KERNELS = {"attention": "attn_f16x3_pipe_kernel<true, true, false>", "gemm_qkv": "gemm_rowln16_kernel<RlGeo<192, 2>, 2, false>",
+           "gemm_fc1_gelu": "gemm_plain256_kernel<1, true, 4, true>", "gemm_proj": "gemm_rowln16_kernel<RlGeo<192, 2>, 0, false>"}
 src = sys.argv[1]
 blocks, cur = {}, None
 for line in open(src):
