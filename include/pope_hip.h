@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define POPE_ABI_VERSION 8
+#define POPE_ABI_VERSION 9
 
 enum {
     POPE_EPI_BIAS = 0,        /* C = A.W^T + bias                         nn.Linear                     */
@@ -119,6 +119,12 @@ int pope_attention_prec_f32(const float* qkv, float* out, int B, int N, int head
  * the output is a convex combination of v rows, so it fits whenever v did): qkv_planes [B*N, 3*heads*64] as written by
  * pope_linear_planes_f32(..., c_planes), out_planes [B*N, heads*64] as read by the proj GEMM.  heads*64 % 32 == 0. */
 int pope_attention_planes_f32(const void* qkv_planes, void* out_planes, int B, int N, int heads, void* stream);
+
+/* POPE_PREC_F16 attention core (BASELINE config 5's dtype; attention.py:51-59 in single-product f16 arithmetic with fp32 scores,
+ * softmax and accumulators): qkv_f16 [B*N, 3*heads*64] f16 row-major holding q * (head_dim^-0.5 * log2 e), k, v — what the QKV
+ * projection of the f16 ViT path writes — -> out_f16 [B*N, heads*64] f16, value * POPE_PLANES_ACT_SCALE (the f16 proj GEMM's
+ * operand).  qkv_f16 and out_f16 16-byte aligned.  (ABI 9.) */
+int pope_attention_f16(const void* qkv_f16, void* out_f16, int B, int N, int heads, void* stream);
 
 /* Measurement only: pope_attention_planes_f32 through a diagnostic instantiation of the same kernel that counts the
  * (wave, 64-key tile) pairs whose softmax reference had to ADVANCE before the tile's exponentials (*exact_passes_host; of

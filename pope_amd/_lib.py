@@ -74,6 +74,7 @@ PROTOTYPES = {
     "pope_attention_prec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pope_patch_embed_planes_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pope_attention_planes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pope_attention_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pope_attention_planes_diag_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, c_ll_p, C.c_void_p]),
     "pope_cls_cosine_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "pope_vit_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
@@ -163,7 +164,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.pope_abi_version() != 8:
+        if handle.pope_abi_version() != 9:
             raise RuntimeError("libpope_hip.so ABI version mismatch")
         _lib = handle
     return _lib

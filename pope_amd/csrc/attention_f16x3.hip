@@ -49,10 +49,8 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
 
 // OUT_PLANES: write the output as f16 hi/lo activation planes (pope_hip.h layout, scale 8) for the
 // f16x3 proj GEMM instead of fp32.
-// PLAIN (POPE_PREC_F16, with OUT_PLANES): single-product f16 arithmetic — q, k, v and the probabilities are rounded to
-// f16 once, ONE MFMA per product, fp32 accumulators and softmax; the output is f16 row-major (value * 8) for the plain
-// proj GEMM (gemm_planes.hip, GemmParams::plain).
-template <bool OUT_PLANES, bool PLAIN = false>
+// (POPE_PREC_F16's single-product attention lives in attention_f16.hip since round 4.)
+template <bool OUT_PLANES>
 __global__ __launch_bounds__(NT, 2) void attn_f16x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                              int N, int heads) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -114,11 +112,6 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             f16x4 hi, lo;
-            if constexpr (PLAIN) {
-                *reinterpret_cast<f16x4*>(Kh + (srow + RPP * i) * KST + scol) = __builtin_convertvector(rk[i], f16x4);
-                *reinterpret_cast<f16x4*>(Vh + (srow + RPP * i) * VST + scol) = __builtin_convertvector(rv[i], f16x4);
-                continue;
-            }
             split4(rk[i], hi, lo);
             *reinterpret_cast<f16x4*>(Kh + (srow + RPP * i) * KST + scol) = hi;
             *reinterpret_cast<f16x4*>(Kl + (srow + RPP * i) * KST + scol) = lo;
@@ -163,14 +156,12 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_kernel(const float* __restri
         for (int kg = 0; kg < 4; ++kg) {
             const f16x8 k0h = *reinterpret_cast<const f16x8*>(kb_h + 16 * kg);
             const f16x8 k1h = *reinterpret_cast<const f16x8*>(kb_h + 32 * KST + 16 * kg);
-            if constexpr (!PLAIN) {
-                const f16x8 k0l = *reinterpret_cast<const f16x8*>(kb_l + 16 * kg);
-                const f16x8 k1l = *reinterpret_cast<const f16x8*>(kb_l + 32 * KST + 16 * kg);
-                s0 = mfma_f16(k0l, qh[kg], s0);
-                s1 = mfma_f16(k1l, qh[kg], s1);
-                s0 = mfma_f16(k0h, ql[kg], s0);
-                s1 = mfma_f16(k1h, ql[kg], s1);
-            }
+            const f16x8 k0l = *reinterpret_cast<const f16x8*>(kb_l + 16 * kg);
+            const f16x8 k1l = *reinterpret_cast<const f16x8*>(kb_l + 32 * KST + 16 * kg);
+            s0 = mfma_f16(k0l, qh[kg], s0);
+            s1 = mfma_f16(k1l, qh[kg], s1);
+            s0 = mfma_f16(k0h, ql[kg], s0);
+            s1 = mfma_f16(k1h, ql[kg], s1);
             s0 = mfma_f16(k0h, qh[kg], s0);
             s1 = mfma_f16(k1h, qh[kg], s1);
         }
@@ -220,12 +211,6 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_kernel(const float* __restri
                     p0[e] = (u ? s1 : s0)[8 * s + e];
                     p1[e] = (u ? s1 : s0)[8 * s + 4 + e];
                 }
-                if constexpr (PLAIN) {
-                    const f16x8 ph = cat(__builtin_convertvector(p0, f16x4), __builtin_convertvector(p1, f16x4));
-                    o0 = mfma_f16(vfrag(Vh, u, s, 0), ph, o0);
-                    o1 = mfma_f16(vfrag(Vh, u, s, 1), ph, o1);
-                    continue;
-                }
                 f16x4 h0, l0, h1, l1;
                 split4(p0, h0, l0);
                 split4(p1, h1, l1);
@@ -266,10 +251,7 @@ __global__ __launch_bounds__(NT, 2) void attn_f16x3_kernel(const float* __restri
         const int qrow = q0 + wave * 32 + lr;
         const f32x4 v = *reinterpret_cast<const f32x4*>(&Os[lr * OST + c4]);
         if (qrow < N) {
-            if constexpr (OUT_PLANES && PLAIN) {   // f16 row-major, value * 8
-                *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(out) + (size_t(b) * N + qrow) * D + head * HD + c4) =
-                    __builtin_convertvector(v * 8.0f, f16x4);
-            } else if constexpr (OUT_PLANES) {
+            if constexpr (OUT_PLANES) {
                 f16x4 hi, lo;
                 split4(v * 8.0f, hi, lo);  // K_PLANES_ACT_SCALE
                 const int col = head * HD + c4;
@@ -832,18 +814,6 @@ int pope_launch_attention_f16x3_planes_io(const void* qkv_planes, void* out_plan
     return pope_check_launch();
 }
 
-// POPE_PREC_F16: fp32 qkv in, plain f16 arithmetic, f16 row-major output (value * 8) [B*N, heads*64]
-int pope_launch_attention_f16_plain(const float* qkv, void* out_f16, int B, int N, int heads, hipStream_t stream) {
-    if (B <= 0 || N <= 0 || heads <= 0 || size_t(B) * heads * ((N + QB - 1) / QB) > 0x7fffffffull) return POPE_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out_f16) & 15)) return POPE_ERR_ARG;
-    if (size_t(N) * 3 * heads * HD * 4 >= (size_t(1) << 32)) return POPE_ERR_ARG;
-    const dim3 grid(unsigned((N + QB - 1) / QB) * heads * B);
-    constexpr size_t lds = X3_ATTN_STAGE_BYTES > X3_ATTN_EPI_BYTES ? X3_ATTN_STAGE_BYTES : X3_ATTN_EPI_BYTES;
-    static pope_dev_mask lds_ok{0};
-    if (!pope_opt_in_lds(attn_f16x3_kernel<true, true>, lds, lds_ok)) return POPE_ERR_LAUNCH;
-    hipLaunchKernelGGL((attn_f16x3_kernel<true, true>), grid, dim3(NT), lds, stream, qkv, static_cast<float*>(out_f16), N, heads);
-    return pope_check_launch();
-}
 
 int pope_launch_attention_f16x3_planes(const float* qkv, void* out_planes, int B, int N, int heads, hipStream_t stream) {
     if ((heads * HD) & 31) return POPE_ERR_ARG;

@@ -193,6 +193,11 @@ int pope_attention_planes_f32(const void* qkv_planes, void* out_planes, int B, i
     return pope_launch_attention_f16x3_planes_io(qkv_planes, out_planes, B, N, heads, static_cast<hipStream_t>(stream));
 }
 
+int pope_attention_f16(const void* qkv_f16, void* out_f16, int B, int N, int heads, void* stream) {
+    StreamDevice on_device(stream);
+    return pope_launch_attention_f16_dma(qkv_f16, out_f16, B, N, heads, static_cast<hipStream_t>(stream));
+}
+
 int pope_attention_planes_diag_f32(const void* qkv_planes, void* out_planes, int B, int N, int heads, long long* exact_passes_host,
                                    void* stream) {
     StreamDevice on_device(stream);
@@ -302,6 +307,7 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
         g.lda = K / 2; g.ldw = K / 2; g.K = K / 2; g.ldc = c_f16 ? N / 2 : N;   // column pairs (GemmParams::plain)
         g.M = rows; g.N = N; g.epilogue = epi; g.gamma = gamma; g.res = res; g.ldres = N;
         g.plain = 1;
+        if (epi == EPI_QKV_F16) { g.sam_dim = N / 3; g.sam_qscale = 0.125f * 1.44269504088896340736f; }   // heads of 64: head_dim^-0.5 * log2 e
         return pope_launch_gemm_nt_f16x3_planes(g, stream);
     };
     // residual GEMM + following LayerNorm: x = res + gamma * (a . W^T + bias); LN(x; ln_w, ln_b) -> planes or fp32
@@ -336,9 +342,11 @@ static int vit_forward_impl(const pope_vit_weights* w, const float* img, int B, 
             POPE_MARK(POPE_K_LAYERNORM);
             POPE_TRY(pope_launch_layernorm_f16(x, k.norm1_w, k.norm1_b, xn_pl, rows, dim, eps, range_flag, stream));
             POPE_MARK(POPE_K_GEMM_QKV);
-            POPE_TRY(plain_gemm(xn_pl, k.qkv_wp, k.qkv_b, qkv, nullptr, 3 * dim, dim, EPI_BIAS, nullptr, nullptr));
+            // q (pre-scaled by head_dim^-0.5 log2 e), k, v leave the QKV epilogue as f16 rows: the attention kernel stages K / V
+            // memory -> LDS directly (attention_f16.hip)
+            POPE_TRY(plain_gemm(xn_pl, k.qkv_wp, k.qkv_b, nullptr, qkv, 3 * dim, dim, EPI_QKV_F16, nullptr, nullptr));
             POPE_MARK(POPE_K_ATTENTION);
-            POPE_TRY(pope_launch_attention_f16_plain(qkv, att, B, ntok, w->heads, stream));
+            POPE_TRY(pope_launch_attention_f16_dma(qkv, att, B, ntok, w->heads, stream));
             POPE_MARK(POPE_K_GEMM_PROJ);
             POPE_TRY(plain_gemm(att, k.proj_wp, k.proj_b, x, nullptr, dim, dim, EPI_BIAS_LS_RES, k.ls1, x));
             POPE_MARK(POPE_K_LAYERNORM);

@@ -257,6 +257,9 @@ int pope_launch_gemm_nt_f16x3_planes(const GemmParams& g, hipStream_t stream) {
         case EPI_BIAS:
         case EPI_BIAS_GELU:
         case EPI_BIAS_RELU: return pope_launch_planes16(g, stream);
+        case EPI_QKV_F16:
+            if (!g.plain || !out_planes || g.sam_dim <= 0 || (g.sam_dim & 63)) return POPE_ERR_ARG;
+            return pope_launch_planes16(g, stream);
         case EPI_BIAS_LS_RES:
             if (!g.res || out_planes || (!g.gamma && g.res_mod <= 0)) return POPE_ERR_ARG;
             return pope_launch_planes16(g, stream);

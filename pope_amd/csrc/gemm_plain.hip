@@ -15,7 +15,7 @@
 //     (0.375 per MFMA; the 128 x 128 kernel in PLAIN mode: 0.5);
 //   * the epilogues are gemm_planes.hip's, sub-tile by sub-tile (LDS-transposed, coalesced, the same arithmetic): results are
 //     bit-identical to the kernel this replaces (tests/test_gpu_ops.py::test_plain256_equals_tile_kernel).
-// Served: EPI_BIAS -> fp32, EPI_BIAS_GELU -> f16, EPI_BIAS_LS_RES -> fp32 (in place), EPI_SAM_QKV; M >= 2 048, K % 64 == 0.
+// Served: EPI_BIAS -> fp32, EPI_BIAS_GELU -> f16, EPI_BIAS_LS_RES -> fp32 (in place), EPI_SAM_QKV, EPI_QKV_F16; M >= 2 048, K % 64 == 0.
 // Everything else (and the implicit 3 x 3 convolution of the neck) stays on gemm_planes16_kernel.
 #include "gemm_core.h"
 #include "kernels.h"
@@ -232,6 +232,8 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
         rsq = __builtin_amdgcn_make_buffer_rsrc(dst, 0, bytes, 0x00020000);
         rmap = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(g.sam_rowmap), 0, unsigned(g.M) * 4u, 0x00020000);
     }
+    [[maybe_unused]] float qkv_scale = 1.0f;
+    if constexpr (EPI == EPI_QKV_F16) qkv_scale = colc < g.sam_dim ? g.sam_qscale : 1.0f;   // a lane's four columns lie in one of q / k / v
     __syncthreads();   // all waves have finished reading the last stage: the LDS is the epilogue's now
     float* E = smem + wave * 32 * EPI_ST;
     f32x2 amax = {0.f, 0.f};
@@ -281,6 +283,11 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
                     pope_amax4x2(amax, v);
                     const unsigned o = col_ok && row0 + 4 * i < unsigned(g.M) ? (sq_dest[i] * unsigned(sq_row_h) + unsigned(sq_c)) * 2u : DROP;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, f16x4)), rsq, o, 0, 0);
+                } else if constexpr (EPI == EPI_QKV_F16) {   // attention operands: f16 row-major, no activation scale (gemm_planes.hip)
+                    v = (v * inv + bias) * qkv_scale;
+                    pope_amax4x2(amax, v);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, f16x4)), rc,
+                                                          col_ok ? off + unsigned(col) * 2u : DROP, 0, 0);
                 } else if constexpr (EPI == EPI_BIAS_GELU) {
                     v = v * inv + bias;
                     const f32x2 g01 = pl_gelu_pair(f32x2{v[0], v[1]}), g23 = pl_gelu_pair(f32x2{v[2], v[3]});
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if constexpr (EPI == EPI_SAM_QKV)   // attention operands carry no scale
+    if constexpr (EPI == EPI_SAM_QKV || EPI == EPI_QKV_F16)   // attention operands carry no scale
         pope_range_flag(g.range_flag, g.range_bit, !(__builtin_fmaxf(amax[0], amax[1]) < POPE_F16_OVERFLOW));
     else if constexpr (OUT_F16)
         pope_range_flag(g.range_flag, g.range_bit, !(__builtin_fmaxf(amax[0], amax[1]) * PL_A_SCALE < POPE_F16_OVERFLOW));
@@ -363,6 +370,7 @@ bool pope_plain256_supported(const GemmParams& g) {
         case EPI_BIAS_GELU: return out_f16;
         case EPI_BIAS_LS_RES: return !out_f16 && g.C && g.res;
         case EPI_SAM_QKV: return out_f16;
+        case EPI_QKV_F16: return out_f16 && g.sam_dim > 0 && !(g.sam_dim & 63);
     }
     return false;
 }
@@ -377,6 +385,7 @@ int pope_launch_plain256(const GemmParams& g, hipStream_t stream) {
         case EPI_BIAS_GELU: return launch_plain_n<EPI_BIAS_GELU, true>(g, stream);
         case EPI_BIAS_LS_RES: return launch_plain_n<EPI_BIAS_LS_RES, false>(g, stream);
         case EPI_SAM_QKV: return launch_plain_n<EPI_SAM_QKV, true>(g, stream);
+        case EPI_QKV_F16: return launch_plain_n<EPI_QKV_F16, true>(g, stream);
     }
     return POPE_ERR_ARG;
 }

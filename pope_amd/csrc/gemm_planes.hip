@@ -362,6 +362,8 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
             rsq = __builtin_amdgcn_make_buffer_rsrc(dst, 0, bytes, 0x00020000);
             rmap = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(g.sam_rowmap), 0, unsigned(g.M) * 4u, 0x00020000);
         }
+        [[maybe_unused]] float qkv_scale = 1.0f;
+        if constexpr (EPI == EPI_QKV_F16) qkv_scale = colc < g.sam_dim ? g.sam_qscale : 1.0f;   // a lane's four columns lie in one of q / k / v
         __syncthreads();  // all waves have finished reading the last K-step stage
         float* E = epi + wave * 32 * EPI_ST;
         f32x2 amax = {0.f, 0.f};  // OUT_PLANES: largest magnitude written as planes (range guard; rows >= M hold finite
@@ -413,6 +415,12 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rsq, o + unsigned(sq_lo) * 2u, 0, 0);
                     }
                     continue;
+                } else if constexpr (EPI == EPI_QKV_F16) {   // attention operands: f16 row-major, no activation scale
+                    v = (v * inv + bias) * qkv_scale;
+                    pope_amax4x2(amax, v);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, f16x4)), rc,
+                                                          col_ok ? off + unsigned(col) * 2u : DROP, 0, 0);
+                    continue;
                 } else if constexpr (EPI == EPI_BIAS_GELU) {
                     v = v * inv + bias;
                     const f32x2 g01 = gelu_erf_pair(f32x2{v[0], v[1]}), g23 = gelu_erf_pair(f32x2{v[2], v[3]});
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (EPI == EPI_SAM_QKV)   // attention operands carry no scale
+        if constexpr (EPI == EPI_SAM_QKV || EPI == EPI_QKV_F16)   // attention operands carry no scale
             pope_range_flag(g.range_flag, g.range_bit, !(__builtin_fmaxf(amax[0], amax[1]) < POPE_F16_OVERFLOW));
         else if constexpr (OUT_PLANES)
             pope_range_flag(g.range_flag, g.range_bit, !(__builtin_fmaxf(amax[0], amax[1]) * A_SCALE < POPE_F16_OVERFLOW));
@@ -565,6 +573,7 @@ int pope_launch_planes16(const GemmParams& g, hipStream_t stream) {
     if (g.plain) {   // single-product f16 (SAM encoder, precision "f16"): the four forms that path uses
         if (g.epilogue == EPI_BIAS && !out_planes) return launch16<EPI_BIAS, false, false, true>(g, stream);
         if (g.epilogue == EPI_BIAS_GELU && out_planes) return launch16<EPI_BIAS_GELU, true, false, true>(g, stream);
+        if (g.epilogue == EPI_QKV_F16 && out_planes) return launch16<EPI_QKV_F16, true, false, true>(g, stream);
         if (g.epilogue == EPI_BIAS_LS_RES && !out_planes) return launch16<EPI_BIAS_LS_RES, false, false, true>(g, stream);
         if (g.epilogue == EPI_CONV && !out_planes && g.conv_cch > 0 && g.K == 9 * 32 * g.conv_cch && g.lda == 32 * g.conv_cch &&
             g.conv_wp >= 3)

@@ -12,6 +12,8 @@ enum GemmEpilogue {
     EPI_BIAS_RELU = 5,    // C = max(A.W^T + bias, 0)                (LoFTR encoder MLP, transformer.py:24-28; gemm_planes.hip only)
     EPI_SIM = 4,          // batched similarity (planes kernel): C[b] = (A[b].W[b]^T * alpha) / divisor, no bias
     EPI_SAM_QKV = 7,      // SAM block's QKV projection written straight into the attention operand planes (sam.hip; gemm_planes.hip only)
+    EPI_QKV_F16 = 8,      // plain f16 only (POPE_PREC_F16 ViT blocks): C = (A.W^T + bias) * (col < sam_dim ? sam_qscale : 1) -> f16 row-major
+                          // [M, N] with NO activation scale: the operand of attention_f16.hip (q carries head_dim^-0.5 * log2 e before its ONE rounding)
     EPI_CONV = 6,         // C = act(A.W^T + bias [+ res_pl]), act(v) = max(v, 0) + act_slope * min(v, 0): ReLU (0), LeakyReLU
                           // (0.01) or identity (1); the ResNet-FPN convolutions (conv.hip; gemm_planes.hip only)
 };
@@ -137,11 +139,12 @@ int pope_launch_gemm_nt_f16x3(const GemmParams& g, hipStream_t stream);
 int pope_launch_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
                               int rows, int dim, float eps, hipStream_t stream);
 
-// POPE_PREC_F16 pieces of the DINOv2 path (sam.hip, attention_f16x3.hip): LayerNorm -> f16 row-major (value * 8); attention with
-// fp32 qkv in, plain f16 arithmetic, f16 row-major output (value * 8)
+// POPE_PREC_F16 pieces of the DINOv2 path (sam.hip, attention_f16.hip): LayerNorm -> f16 row-major (value * 8); attention on the f16
+// operands of the QKV epilogue, f16 row-major output (value * 8)
 int pope_launch_layernorm_f16(const float* x, const float* w, const float* b, void* y_f16, int rows, int dim, float eps, unsigned* flag,
                               hipStream_t stream);
-int pope_launch_attention_f16_plain(const float* qkv, void* out_f16, int B, int N, int heads, hipStream_t stream);
+// round 4: f16 qkv in (EPI_QKV_F16), LDS-direct K / V staging, four stages, software-pipelined (attention_f16.hip)
+int pope_launch_attention_f16_dma(const void* qkv_f16, void* out_f16, int B, int N, int heads, hipStream_t stream);
 // Multi-head softmax attention over qkv[B, N, 3, heads, 64] -> out[B, N, heads*64].
 int pope_launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream);
 int pope_launch_attention_f16x3(const float* qkv, float* out, int B, int N, int heads, hipStream_t stream);

@@ -1,0 +1,41 @@
+"""Dev: BASELINE config 5's two models in their stated dtype (precision "f16"), a few forward passes each, for rocprofv3
+--kernel-trace --stats: `python scripts/config5_prof.py [vit_l|sam_h] [iters]` (bench.py's config5 leg times the same calls)."""
+import os
+import sys
+from functools import partial
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pope_amd import dinov2, synth  # noqa: E402
+from pope_amd.sam_encoder import ImageEncoderViT  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "vit_l"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device("cuda:0")
+if which == "vit_l":
+    m = dinov2.vit_large(patch_size=14, img_size=518, init_values=1e-5, ffn_layer="mlp", block_chunks=0)
+    m.load_state_dict(synth.synthetic_state_dict(seed=0, dim=1024, depth=24), strict=True)
+    m = m.eval().to(dev)
+    m.precision = "f16"
+    x = synth.synthetic_images(21, 476, 630, seed=3, device=dev)
+    fn = lambda: m(x, is_training=True)["x_norm_patchtokens"]
+else:
+    gidx = (7, 15, 23, 31)
+    m = ImageEncoderViT(depth=32, embed_dim=1280, img_size=1024, mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+                        num_heads=16, patch_size=16, qkv_bias=True, use_rel_pos=True, global_attn_indexes=list(gidx),
+                        window_size=14, out_chans=256)
+    m.load_state_dict(synth.synthetic_sam_encoder_state_dict(seed=0, global_idx=gidx), strict=True)
+    m = m.eval().to(dev)
+    m.precision = "f16"
+    x = synth.synthetic_images(8, 1024, 1024, seed=3, device=dev)
+    fn = lambda: m(x)
+fn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    y = fn()
+e1.record()
+torch.cuda.synchronize()
+print(which, "ms per image", e0.elapsed_time(e1) / iters / x.size(0), "finite", bool(torch.isfinite(y).all()))

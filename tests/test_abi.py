@@ -39,7 +39,7 @@ def test_code_object_is_gfx950():
 
 
 def test_abi_version_and_errors(hip_lib):
-    assert hip_lib.pope_abi_version() == 8
+    assert hip_lib.pope_abi_version() == 9
     assert hip_lib.pope_error_string(0) == b"ok"
     assert b"workspace" in hip_lib.pope_error_string(-3)
 

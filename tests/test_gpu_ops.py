@@ -144,6 +144,41 @@ def test_attention_error_vs_fp64(dev, prec):
     assert err < 2e-5
 
 
+@pytest.mark.parametrize("B,N,heads,spike", [(2, 1531, 6, False), (1, 197, 16, False), (3, 64, 2, False), (1, 1, 1, False),
+                                             (1, 130, 4, False), (1, 1531, 2, True)])
+def test_attention_f16_on_f16_operands(dev, hip_lib, B, N, heads, spike):
+    """pope_attention_f16 (POPE_PREC_F16, attention_f16.hip: LDS-direct K / V staging, four stages, in-wave pipeline) against
+    fp64 attention computed from THE SAME f16-rounded operands: what is left is the rounding of P to f16 and of the output to
+    f16 (both <= 2^-11 relative).  Shapes: the bench's key count, one / two / three-tile sequences with ragged ends (the
+    prologue, the tail mask and every wait-count branch), a single key; `spike`: a key whose score jumps by 25 log2 units at
+    a late tile, so that the running maximum moves by a large factor mid-sequence (o and l rescaled)."""
+    import ctypes as C
+    D = heads * 64
+    g = torch.Generator().manual_seed(1000 * N + heads)
+    q = torch.randn(B, N, heads, 64, generator=g) * 1.2
+    k = torch.randn(B, N, heads, 64, generator=g) * 1.2
+    v = torch.randn(B, N, heads, 64, generator=g) * 2.0
+    if spike:
+        k[:, N - 200] = 6.0 * q[:, 5]          # query 5 (and its neighbours in direction) suddenly find a huge key
+    qs = (q * (0.125 * 1.4426950408889634)).half()     # what the QKV epilogue writes: q * head_dim^-0.5 * log2 e, ONE rounding
+    kh, vh = k.half(), v.half()
+    qkv = torch.stack([qs, kh, vh], 2).reshape(B * N, 3 * D).contiguous().to(dev)
+    out = torch.full((B * N + 3, D), 7.0, dtype=torch.float16, device=dev)     # three guard rows
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        assert hip_lib.pope_attention_f16(C.c_void_p(qkv.data_ptr()), C.c_void_p(out.data_ptr()), B, N, heads, st) == 0
+    torch.cuda.synchronize()
+    assert bool((out[B * N:] == 7.0).all())
+    s = torch.einsum("bqhd,bkhd->bhqk", qs.double(), kh.double())              # log2-domain scores
+    p = torch.exp2(s - s.amax(-1, keepdim=True))
+    want = torch.einsum("bhqk,bkhd->bqhd", p / p.sum(-1, keepdim=True), vh.double()).reshape(B * N, D)
+    got = out[:B * N].cpu().double() / 8.0
+    err = float((got - want).abs().max())
+    print(f"attention f16 B={B} N={N} heads={heads}: max |err| vs fp64 on the same operands = {err:.2e} (|out| max {float(want.abs().max()):.2f})")
+    assert err < 3e-3 * max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().mean()) < 2e-4 * max(1.0, float(want.abs().max()))
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_attention_online_softmax_rescale_branch(dev, prec):
     # force the running max to jump at a late key tile (spiked key), so the rescale of O and l is

@@ -228,7 +228,7 @@ def test_f16_mode_is_batch_invariant_across_the_gemm_switch(hip_lib, sd0):
     """precision "f16" has two GEMM mainloops: gemm_planes16_kernel's 128 x 128 tiles (small M) and gemm_plain.hip's 256-row tiles
     with LDS-direct staging (M >= 2 048; round 4).  Both accumulate every output in the same order and share the epilogue
     arithmetic: an image must come out bit-identical alone (257 rows: the tile kernel) and inside a batch of nine (2 313 rows:
-    the new kernel for QKV -> fp32, FC1 . GELU -> f16, proj / FC2 + residual)."""
+    the new kernel for QKV -> f16 attention operands, FC1 . GELU -> f16, proj / FC2 + residual); the attention kernel (attention_f16.hip) is the same at every batch."""
     from pope_amd import synth
     from pope_amd.dinov2_utils import load_dinov2_model
     m = load_dinov2_model(state_dict=sd0).to("cuda:0")
