@@ -554,7 +554,7 @@ def roofline_entry(dominant, dom, peak_tflops, mfma_factor, chunk, pmc=True):
 def config5_leg(device, iters=3):
     """BASELINE config 5 as two timed forward passes on synthetic weights and inputs (never part of `value`): the
     DINOv2 backbone swapped to ViT-L/14 on 640 x 480 crops (476 x 630, 21 images per launch sequence) and the SAM
-    ViT-H image encoder on 1024 x 1024 (4 images).  Each figure carries a self-check: finite outputs and image 0 of the
+    ViT-H image encoder on 1024 x 1024 (12 images per launch sequence).  Each figure carries a self-check: finite outputs and image 0 of the
     batch bit-equal to its own single-image run.  A failure is reported in place, the headline line stands."""
     from functools import partial
     from pope_amd import dinov2, synth
@@ -605,7 +605,8 @@ def config5_leg(device, iters=3):
                               window_size=14, out_chans=256)
         enc.load_state_dict(synth.synthetic_sam_encoder_state_dict(seed=0, global_idx=gidx), strict=True)
         enc = enc.eval().to(device)
-        SB = 8   # images per launch sequence (ImageEncoderViT.max_batch): 128 row tiles of 256 for the long-K GEMMs
+        SB = 12   # images per launch sequence: 192 row tiles of 256 -> 3.75 / 11.25 / 15 rounds of the 256 x 256 GEMM tiles (8 images: 2.5 / 7.5 / 10)
+        enc.max_batch = SB
         x = synth.synthetic_images(SB, 1024, 1024, seed=3, device=device)
         n, dim, hd, heads = 4096, 1280, 80, 16
         lin = n * (768 * dim + 32 * 12 * dim * dim + dim * 256 + 9 * 256 * 256)

@@ -80,7 +80,18 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
     const int l15 = lane & 15, q4 = lane >> 4;
     const int tiles_n = (g.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * PL_BM, n0 = (tile % tiles_n) * BN;
+    // L2-aware order (round 4): the 32 workgroups an XCD runs at a time are consecutive logical ids; walked row-tile-major
+    // inside groups of GROUP_M row tiles they form a 4 x 8 block of tiles — per K-step 12 distinct 32 KB operand panels for 32
+    // CUs instead of ~22 (1.6 row tiles x 20 column tiles of a plain row-major walk at N = 5 120): the long-K weights of config
+    // 5 (13 MB, four L2s' worth) come through the fabric once per XCD and group.  Worth 1 - 2 % (SAM ViT-H f16 8.16 -> 8.00 ms
+    // per image, ViT-L/14 1.495 -> 1.475; groups of 8: 8.07 / 1.463, of 16: 8.30 / 1.498; profiles/r04/config5_tile_order_ab.txt):
+    // these GEMMs are not waiting on L2 misses.
+    constexpr int GROUP_M = 4;
+    const int tiles_m = (g.M + PL_BM - 1) / PL_BM, per_group = GROUP_M * tiles_n;
+    const int group = tile / per_group, first_m = group * GROUP_M, in_group = tile - group * per_group;
+    const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+    const int pid_n = in_group / gm, pid_m = first_m + in_group - pid_n * gm;
+    const int m0 = pid_m * PL_BM, n0 = pid_n * BN;
     const unsigned lda4 = unsigned(g.lda) * 4u, ldw4 = unsigned(g.ldw) * 4u;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, unsigned(g.M) * lda4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, unsigned(g.N) * ldw4, 0x00020000);

@@ -12,13 +12,14 @@ from pope_amd.sam_encoder import ImageEncoderViT  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "vit_l"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+SB = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # images per launch sequence (0: 21 for vit_l, 8 for sam_h)
 dev = torch.device("cuda:0")
 if which == "vit_l":
     m = dinov2.vit_large(patch_size=14, img_size=518, init_values=1e-5, ffn_layer="mlp", block_chunks=0)
     m.load_state_dict(synth.synthetic_state_dict(seed=0, dim=1024, depth=24), strict=True)
     m = m.eval().to(dev)
     m.precision = "f16"
-    x = synth.synthetic_images(21, 476, 630, seed=3, device=dev)
+    x = synth.synthetic_images(SB or 21, 476, 630, seed=3, device=dev)
     fn = lambda: m(x, is_training=True)["x_norm_patchtokens"]
 else:
     gidx = (7, 15, 23, 31)
@@ -28,7 +29,8 @@ else:
     m.load_state_dict(synth.synthetic_sam_encoder_state_dict(seed=0, global_idx=gidx), strict=True)
     m = m.eval().to(dev)
     m.precision = "f16"
-    x = synth.synthetic_images(8, 1024, 1024, seed=3, device=dev)
+    m.max_batch = SB or 8
+    x = synth.synthetic_images(SB or 8, 1024, 1024, seed=3, device=dev)
     fn = lambda: m(x)
 fn()
 torch.cuda.synchronize()
