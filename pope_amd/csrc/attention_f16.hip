@@ -27,10 +27,6 @@
 #include "kernels.h"
 #include <type_traits>
 
-#ifndef AF_LAB
-#define AF_LAB 0   // lab builds (timing only, wrong results): 1 no exponentials, 2 no staging after the prologue, 4 no P.V MFMAs, 8 no join, 16 no score MFMAs
-#endif
-
 namespace {
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -249,7 +245,7 @@ __global__ __launch_bounds__(NT, 2) void attn_f16_dma_kernel(const _Float16* __r
         // tile t - 1's stage
         __builtin_amdgcn_s_waitcnt(0x0F70);
         raw_barrier();
-        if (!(AF_LAB & 2)) dma_tile(t + 3);                   // one iteration to land
+        dma_tile(t + 3);                  // one iteration to land
         const int st_cur = t % NST, st_next2 = (t + 2) % NST;
         f32x2 ls[NQ];
 #pragma unroll
@@ -258,10 +254,8 @@ __global__ __launch_bounds__(NT, 2) void attn_f16_dma_kernel(const _Float16* __r
         auto exp_pair = [&](int qb, int idx) __attribute__((always_inline)) {
             f32x16& c = sb[P][qb][idx < 8 ? 0 : 1];
             const int e = 2 * (idx & 7);
-            if (!(AF_LAB & 1)) {
-                c[e] = __builtin_amdgcn_exp2f(c[e]);
-                c[e + 1] = __builtin_amdgcn_exp2f(c[e + 1]);
-            }
+            c[e] = __builtin_amdgcn_exp2f(c[e]);
+            c[e + 1] = __builtin_amdgcn_exp2f(c[e + 1]);
             ls[qb] += f32x2{c[e], c[e + 1]};
             asm volatile("" : "+v"(ls[qb]));   // keep the running sum in its slot (the optimiser otherwise sinks the chain behind the MFMAs)
         };
@@ -273,7 +267,7 @@ __global__ __launch_bounds__(NT, 2) void attn_f16_dma_kernel(const _Float16* __r
             const int kg = i >> 1, j = i & 1;
 #pragma unroll
             for (int qb = 0; qb < NQ; ++qb) {
-                if (has_next && !(AF_LAB & 16)) sb[P ^ 1][qb][j] = mfma_f16(kreg[kg][j], qf[qb][kg], kg == 0 ? zero : sb[P ^ 1][qb][j]);
+                if (has_next) sb[P ^ 1][qb][j] = mfma_f16(kreg[kg][j], qf[qb][kg], kg == 0 ? zero : sb[P ^ 1][qb][j]);
                 if (qb == 0) read_v(st_cur, i >> 1, i & 1);
                 exp_pair(qb, 2 * i);
                 exp_pair(qb, 2 * i + 1);
@@ -311,7 +305,7 @@ __global__ __launch_bounds__(NT, 2) void attn_f16_dma_kernel(const _Float16* __r
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int qb = 0; qb < NQ; ++qb) {
-                    if (!(AF_LAB & 4)) o[qb][dt] = mfma_f16(vcat(vreg[g][dt]), ph[qb], o[qb][dt]);
+                    o[qb][dt] = mfma_f16(vcat(vreg[g][dt]), ph[qb], o[qb][dt]);
                     if (has_next2 && dt == 0 && qb == 0) read_k(st_next2, g);
                     if (has_next) {
                         const f32x16 &n0 = sb[P ^ 1][qb][0], &n1 = sb[P ^ 1][qb][1];
@@ -324,7 +318,7 @@ __global__ __launch_bounds__(NT, 2) void attn_f16_dma_kernel(const _Float16* __r
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
-        if (has_next && !(AF_LAB & 8)) {
+        if (has_next) {
 #pragma unroll
             for (int qb = 0; qb < NQ; ++qb) join(qb, mt[qb], sb[P ^ 1][qb][0], sb[P ^ 1][qb][1]);
         }

@@ -1,5 +1,5 @@
 """Dev: time pope_attention_f16 (attention_f16.hip) alone at the ViT-L/14 shape of BASELINE config 5 (21 images x 16 heads x 1531
-tokens); POPE_LIB_PATH selects a lab build (scripts/attn_f16_ab.sh).  Prints ms per launch and the fraction of the f16 peak."""
+tokens).  Prints ms per launch and the fraction of the f16 peak."""
 import ctypes as C
 import os
 import sys
