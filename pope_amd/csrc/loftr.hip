@@ -79,9 +79,12 @@ __global__ __launch_bounds__(256) void linattn_finish_kernel(const float* __rest
 // msg[l, h, v] = (sum_d Q[l,h,d] KV[h][d][v]) * (1 / (sum_d Q[l,h,d] Ksum[h][d] + eps)) * S,  Q = elu(q) + 1.
 // Block: 256 threads = 256 / C rows at a time; a thread owns one output column and keeps its KV column and its head's
 // Ksum in registers across the block's rows.
-template <int D>
+// PLANES (round 4): the message leaves as activation planes — the merge GEMM's operand — instead of fp32 + a split_planes pass
+// (the same hi / lo arithmetic: bit-identical planes, one launch and two passes over the tensor less per layer)
+template <int D, bool PLANES>
 __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restrict__ q, const float* __restrict__ kvf, int L, int C, int H,
-                                                             int S, float eps, float* __restrict__ msg, int rows_per_block) {
+                                                             int S, float eps, float* __restrict__ msg, int rows_per_block,
+                                                             unsigned* range_flag) {
     __shared__ float Qs[2][256];
     const int rpp = 256 / C;                          // rows per pass (C = 256: 1, C = 128: 2)
     const int sub = threadIdx.x / C, col = threadIdx.x - sub * C;
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restr
         ksum[d] = kvh[D * D + d];
     }
     const float len = float(S);
+    float amax = 0.f;
     for (int r = 0; r < rows_per_block; r += rpp) {
         const int l = l0 + r + sub;
         const bool ok = l < L && r + sub < rows_per_block;
@@ -108,8 +112,22 @@ __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restr
             num += qh[d] * kvc[d];
             den += qh[d] * ksum[d];
         }
-        if (ok) msg[(size_t(n) * L + l) * C + col] = num * (1.0f / (den + eps)) * len;
+        const float m = num * (1.0f / (den + eps)) * len;
+        if constexpr (PLANES) {
+            if (ok) {
+                const float sv = m * K_PLANES_ACT_SCALE;
+                amax = fmaxf(amax, fabsf(sv));
+                if (!(sv == sv)) amax = INFINITY;
+                const _Float16 hi = _Float16(sv), lo = _Float16(sv - float(hi));
+                _Float16* o = reinterpret_cast<_Float16*>(msg) + (size_t(n) * L + l) * 2 * C + (col >> 5) * 64 + (col & 31);
+                o[0] = hi;
+                o[32] = lo;
+            }
+        } else {
+            if (ok) msg[(size_t(n) * L + l) * C + col] = m;
+        }
     }
+    if constexpr (PLANES) pope_range_flag(range_flag, POPE_RANGE_INPUT, !(amax < POPE_F16_OVERFLOW));
 }
 
 // planes row [x | LayerNorm(m) * w + b] of width 2C (the MLP's input cat[x, message], transformer.py:54), one wave per
@@ -269,10 +287,16 @@ int pope_launch_loftr_layer(const LoftrLayerParams& p, hipStream_t stream) {
     else hipLaunchKernelGGL(linattn_reduce_kernel<16>, dim3(p.n * H, chunks), dim3(256), 0, stream, kv, p.S, C, H, 0.f, part, chunks);
     hipLaunchKernelGGL(linattn_finish_kernel, dim3(p.n * H, (per + 255) / 256), dim3(256), 0, stream, part, chunks, per, kvf);
     const int rpb = 16;
-    if (D == 32) hipLaunchKernelGGL(linattn_apply_kernel<32>, dim3(p.n, (p.L + rpb - 1) / rpb), dim3(256), 0, stream, q, kvf, p.L, C, H, p.S, 1e-6f, msg, rpb);
-    else hipLaunchKernelGGL(linattn_apply_kernel<16>, dim3(p.n, (p.L + rpb - 1) / rpb), dim3(256), 0, stream, q, kvf, p.L, C, H, p.S, 1e-6f, msg, rpb);
-    if (f32) msgp = msg;
-    else LT(pope_launch_split_planes(msg, msgp, int(rx), C, K_PLANES_ACT_SCALE, p.range_flag, stream));
+    // (f16x3: the message is written as planes straight away; fp32 mode: plain rows)
+#define LA_APPLY(DD, PL, DST) hipLaunchKernelGGL((linattn_apply_kernel<DD, PL>), dim3(p.n, (p.L + rpb - 1) / rpb), dim3(256), 0, stream, q, kvf, p.L, \
+                                                 C, H, p.S, 1e-6f, DST, rpb, p.range_flag)
+    if (f32) {
+        if (D == 32) LA_APPLY(32, false, msg); else LA_APPLY(16, false, msg);
+        msgp = msg;
+    } else {
+        if (D == 32) LA_APPLY(32, true, static_cast<float*>(msgp)); else LA_APPLY(16, true, static_cast<float*>(msgp));
+    }
+#undef LA_APPLY
     // 5. merge (-> q buffer), 6. cat[x, LN1(merge)] as planes
     LT(gemm(msgp, Wm, q, nullptr, int(rx), C, C, EPI_BIAS));
     const dim3 rows4(unsigned((rx + 3) / 4));
