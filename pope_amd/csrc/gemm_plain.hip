@@ -86,7 +86,10 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
     // 5 (13 MB, four L2s' worth) come through the fabric once per XCD and group.  Worth 1 - 2 % (SAM ViT-H f16 8.16 -> 8.00 ms
     // per image, ViT-L/14 1.495 -> 1.475; groups of 8: 8.07 / 1.463, of 16: 8.30 / 1.498; profiles/r04/config5_tile_order_ab.txt):
     // these GEMMs are not waiting on L2 misses.
-    constexpr int GROUP_M = 4;
+    // (f16x3 planes mode — the ViT-S/14 FC1, whose 2.4 MB of weights stay in L2 anyway — keeps the row-major walk: there the
+    // grouped order only spreads a row tile's column siblings over more row tiles in flight: fabric traffic 905 -> 1 010 MB per
+    // launch at unchanged time, profiles/r04/pmc_summary.txt history)
+    constexpr int GROUP_M = X3 ? 1 : 4;
     const int tiles_m = (g.M + PL_BM - 1) / PL_BM, per_group = GROUP_M * tiles_n;
     const int group = tile / per_group, first_m = group * GROUP_M, in_group = tile - group * per_group;
     const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
