@@ -110,11 +110,13 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
     for (int i = 0; i < 4; ++i) va[i] = unsigned(m0 + 32 * wave + 8 * i + r8) * lda4 + unsigned(piece) * 16u;
 #pragma unroll
     for (int i = 0; i < NIW; ++i) vw[i] = unsigned(n0 + (BN / 8) * wave + 8 * i + r8) * ldw4 + unsigned(piece) * 16u;
+// (f16x3 planes mode: the activation rows are loaded sc0 nt — FC1 fabric traffic 900 -> 808 MB per launch = 1.07 x algorithmic,
+    // FC1 -2 %, and the FC2 launch behind it -3.5 %: profiles/r04/cache_policy_ab.txt)
 #define PL_DMA(stage, koff)                                                                                                      \
     do {                                                                                                                         \
         _Float16* S_ = lds + (stage) * STAGE;                                                                                    \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                         \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (pl_lds_ptr)(S_ + (32 * wave + 8 * i_) * 64), 16, va[i_], (koff), 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (pl_lds_ptr)(S_ + (32 * wave + 8 * i_) * 64), 16, va[i_], (koff), 0, X3 ? 3 : 0); \
         _Pragma("unroll") for (int i_ = 0; i_ < NIW; ++i_)                                                                       \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (pl_lds_ptr)(S_ + (PL_BM + (BN / 8) * wave + 8 * i_) * 64), 16, vw[i_], (koff), 0, 0); \
     } while (0)

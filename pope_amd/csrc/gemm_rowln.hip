@@ -192,7 +192,7 @@ __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g
         const unsigned vw0 = unsigned(WROWS * wave + r8) * ldw4 + unsigned(piece) * 16u;
 #pragma unroll
         for (int i = 0; i < NIA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(S_ + (AROWS * wave + 8 * i) * ROWB), 16, vt + i * a8, unsigned(kt_) * 128u, 0, LN ? 3 : 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(S_ + (AROWS * wave + 8 * i) * ROWB), 16, vt + i * a8, unsigned(kt_) * 128u, 0, LN ? 3 : 0);   // (planes modes: the column siblings share the rows through L2; nt there: QKV +4.5 % slower)
 #pragma unroll
         for (int i = 0; i < NIW; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_ptr)(S_ + (RM + WROWS * wave + 8 * i) * ROWB), 16, vw0, ko + i * w8, 0, 0);
