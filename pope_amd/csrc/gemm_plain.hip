@@ -67,7 +67,10 @@ __device__ __forceinline__ f32x2 pl_gelu_pair(f32x2 x) {
 // X3: the operands are f16x3 PLANES (a row's K-step = [32 hi | 32 lo] halves — the same 128 bytes per row and K-step as 64
 // plain f16 columns, so staging, LDS image and fragment addresses are shared): three MFMAs per product (lo.hi, hi.lo, hi.hi,
 // gemm_planes.hip's order), planes output.
-template <int EPI, bool OUT_F16, int NWN, bool X3 = false>
+// CONV (with X3, EPI_CONV; round 4): the implicit 3 x 3 stride-1 convolution of conv.hip — K-step (chunk, tap) reads the A rows
+// shifted by (dy * Wp + dx) rows, a scalar offset of the staging instructions; chunk-major K order and W's own K offset as in
+// gemm_planes.hip (DESIGN.md findings 19, 27)
+template <int EPI, bool OUT_F16, int NWN, bool X3 = false, bool CONV = false>
 __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmParams g) {
     constexpr int BN = 64 * NWN, SUB = NWN / 2, ROWS = PL_BM + BN, NST = pl_stages(BN);
     constexpr int STAGE = ROWS * 64;   // halves per stage: 128-byte rows, A rows then W rows
@@ -96,7 +99,8 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
     const int pid_n = in_group / gm, pid_m = first_m + in_group - pid_n * gm;
     const int m0 = pid_m * PL_BM, n0 = pid_n * BN;
     const unsigned lda4 = unsigned(g.lda) * 4u, ldw4 = unsigned(g.ldw) * 4u;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, unsigned(g.M) * lda4, 0x00020000);
+    const unsigned a_rows = CONV ? unsigned(g.M) + 2u * unsigned(g.conv_wp) + 2u : unsigned(g.M);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, a_rows * lda4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, unsigned(g.N) * ldw4, 0x00020000);
     const int nk = g.K / 32;   // K counts 64-bit column pairs (GemmParams::plain): a K-step = 32 pairs = 64 columns = 128 B per row
 
@@ -112,14 +116,23 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
     for (int i = 0; i < NIW; ++i) vw[i] = unsigned(n0 + (BN / 8) * wave + 8 * i + r8) * ldw4 + unsigned(piece) * 16u;
 // (f16x3 planes mode: the activation rows are loaded sc0 nt — FC1 fabric traffic 900 -> 808 MB per launch = 1.07 x algorithmic,
     // FC1 -2 %, and the FC2 launch behind it -3.5 %: profiles/r04/cache_policy_ab.txt)
-#define PL_DMA(stage, koff)                                                                                                      \
+#define PL_DMA2(stage, aoff, woff)                                                                                                \
     do {                                                                                                                         \
         _Float16* S_ = lds + (stage) * STAGE;                                                                                    \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                         \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (pl_lds_ptr)(S_ + (32 * wave + 8 * i_) * 64), 16, va[i_], (koff), 0, X3 ? 3 : 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (pl_lds_ptr)(S_ + (32 * wave + 8 * i_) * 64), 16, va[i_], (aoff), 0, X3 && !CONV ? 3 : 0); \
         _Pragma("unroll") for (int i_ = 0; i_ < NIW; ++i_)                                                                       \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (pl_lds_ptr)(S_ + (PL_BM + (BN / 8) * wave + 8 * i_) * 64), 16, vw[i_], (koff), 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (pl_lds_ptr)(S_ + (PL_BM + (BN / 8) * wave + 8 * i_) * 64), 16, vw[i_], (woff), 0, 0); \
     } while (0)
+    // K-step k: plain / planes GEMM: both operands at k * 128 bytes; CONV: chunk = k / 9, tap = k % 9 = (dy, dx)
+    auto stage_kstep = [&](int stage, int k) {
+        if constexpr (CONV) {
+            const int chunk = k / 9, tap = k - 9 * chunk, dy = tap / 3, dx = tap - 3 * dy;
+            PL_DMA2(stage, unsigned(dy * g.conv_wp + dx) * lda4 + unsigned(chunk) * 128u, unsigned(tap * g.conv_cch + chunk) * 128u);
+        } else {
+            PL_DMA2(stage, k * 128, k * 128);
+        }
+    };
 
     // fragment of a 16-row block: row l15, K-chunk q4 of half h of the K-step
     const int a_row = (wm * 64 * SUB + l15) * 64, w_row = (PL_BM + wn * 64 + l15) * 64;
@@ -135,14 +148,14 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
 
     // NST stages, NST - 1 K-steps in flight: the narrow tiles (long-K FC2 reads its 168 MB activation from MALL / HBM: a single
     // K-step of ~1 000 cycles does not cover that latency) run three stages, the 256-column tiles two
-    PL_DMA(0, 0);
-    if (NST == 3 && nk > 1) PL_DMA(1, 128);
+    stage_kstep(0, 0);
+    if (NST == 3 && nk > 1) stage_kstep(1, 1);
     for (int kt = 0; kt < nk; ++kt) {
         // this wave's pieces of stage kt have landed (the younger K-step's 4 + NIW instructions may still be in flight) ...
         if (NST == 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | (4 + NIW));
         else __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();   // ... and everyone's; every wave has left the stage of K-step kt - 1, which the next DMA overwrites
-        if (kt + NST - 1 < nk) PL_DMA((kt + NST - 1) % NST, (kt + NST - 1) * 128);
+        if (kt + NST - 1 < nk) stage_kstep((kt + NST - 1) % NST, kt + NST - 1);
         const _Float16* S = lds + (kt % NST) * STAGE;
         // A K-step = 2 halves x SUB sub-tiles x 4 row blocks = U units of one activation fragment and four MFMAs (against the
         // half's four W fragments).  A wave that reads a fragment right before its MFMAs waits out the LDS latency every
@@ -248,6 +261,11 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
         rsq = __builtin_amdgcn_make_buffer_rsrc(dst, 0, bytes, 0x00020000);
         rmap = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(g.sam_rowmap), 0, unsigned(g.M) * 4u, 0x00020000);
     }
+    // EPI_CONV: the residual arrives as activation planes (an empty descriptor — no residual — reads zeros); planes rows are wider
+    // than N when the channel count is no multiple of 32 (196 -> 224): the padding columns must read as zeros
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rresp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(EPI == EPI_CONV ? g.res_pl : nullptr), 0, EPI == EPI_CONV && g.res_pl ? unsigned(g.M) * unsigned(g.ldres_pl) * 4u : 0u, 0x00020000);
+    [[maybe_unused]] const bool col_pad = EPI == EPI_CONV && OUT_F16 && !col_ok && col < g.ldc;
     [[maybe_unused]] float qkv_scale = 1.0f;
     if constexpr (EPI == EPI_QKV_F16) qkv_scale = colc < g.sam_dim ? g.sam_qscale : 1.0f;   // a lane's four columns lie in one of q / k / v
     __syncthreads();   // all waves have finished reading the last stage: the LDS is the epilogue's now
@@ -277,6 +295,16 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
                 for (int i = 0; i < 8; ++i)
                     sq_dest[i] = __builtin_amdgcn_raw_buffer_load_b32(rmap, (row0 + 4 * i) * 4u, 0, 0) + unsigned(sq_head * g.sam_npad);
             }
+            if constexpr (EPI == EPI_CONV) {   // shortcut rows: (hi + lo) / 8 (gemm_planes.hip's arithmetic)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned o = (row0 + 4 * i) * unsigned(g.ldres_pl) * 4u + unsigned((col >> 5) * 128 + (col & 31) * 2);
+                    const f16x4 rh = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rresp, col_ok ? o : DROP, 0, 0));
+                    const f16x4 rl = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rresp, col_ok ? o + 64u : DROP, 0, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) res[i][e] = (float(rh[e]) + float(rl[e])) * (1.0f / PL_A_SCALE);
+                }
+            }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -299,6 +327,21 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
                     pope_amax4x2(amax, v);
                     const unsigned o = col_ok && row0 + 4 * i < unsigned(g.M) ? (sq_dest[i] * unsigned(sq_row_h) + unsigned(sq_c)) * 2u : DROP;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, f16x4)), rsq, o, 0, 0);
+                } else if constexpr (EPI == EPI_CONV) {
+                    v = (v * inv + bias) + res[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(v[e], 0.f) + g.act_slope * __builtin_fminf(v[e], 0.f);
+                    if constexpr (OUT_F16) {   // planes (X3), with the zero channel padding
+                        f16x4 hi, lo;
+                        pope_amax4x2(amax, v);
+                        pope_split4(v * PL_A_SCALE, hi, lo);
+                        if (col_pad) { hi = f16x4{0, 0, 0, 0}; lo = f16x4{0, 0, 0, 0}; }
+                        const unsigned o = col_ok || col_pad ? off + unsigned((col >> 5) * 128 + (col & 31) * 2) : DROP;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rc, o, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rc, o + 64u, 0, 2);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, col_ok ? off + unsigned(col) * 4u : DROP, 0, 2);
+                    }
                 } else if constexpr (EPI == EPI_QKV_F16) {   // attention operands: f16 row-major, no activation scale (gemm_planes.hip)
                     v = (v * inv + bias) * qkv_scale;
                     pope_amax4x2(amax, v);
@@ -358,7 +401,37 @@ int launch_x3(const GemmParams& g, hipStream_t stream) {
     return pope_check_launch();
 }
 
+template <bool OUT_PL, int NWN>
+int launch_conv(const GemmParams& g, hipStream_t stream) {
+    constexpr int BN = 64 * NWN;
+    static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
+    if (!pope_opt_in_lds(gemm_plain256_kernel<EPI_CONV, OUT_PL, NWN, true, true>, pl_lds_bytes(BN), lds_ok)) return POPE_ERR_LAUNCH;
+    const int tiles = ((g.M + PL_BM - 1) / PL_BM) * ((g.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_plain256_kernel<EPI_CONV, OUT_PL, NWN, true, true>), dim3(tiles), dim3(PL_THREADS), pl_lds_bytes(BN), stream, g);
+    return pope_check_launch();
+}
+
 }  // namespace
+
+// the implicit 3 x 3 convolutions of the LoFTR CNN (conv.hip) at batch size: 256-row tiles, 128 (N <= 128) or 256 columns
+bool pope_wide_conv_supported(const GemmParams& g) {
+    if (g.plain || !g.a_pl || !g.w_pl || g.epilogue != EPI_CONV || g.conv_cch <= 0 || g.nbatch > 1) return false;
+    if (g.K != 9 * 32 * g.conv_cch || g.lda != 32 * g.conv_cch || g.conv_wp < 3 || (g.ldw & 31) || (g.ldc & 31)) return false;
+    if ((g.c_pl == nullptr) == (g.C == nullptr) || g.N > 256) return false;
+    const int bn = g.N <= 128 ? 128 : 256;
+    // from one round of the CUs: with 36 - 72 K-steps per tile the epilogue that nothing runs under is a few per cent (ResNet-FPN call
+    // at 48 images 12.1 -> 10.9 - 11.2 ms, at the drivers' 6 images 2.08 -> 1.97; thresholds of 4 / 2 / 1 rounds: profiles/r04/conv_wide_ab.txt)
+    return size_t((g.M + PL_BM - 1) / PL_BM) * ((g.N + bn - 1) / bn) >= size_t(pope_cu_count());
+}
+
+int pope_launch_wide_conv(const GemmParams& g, hipStream_t stream) {
+    if (!pope_wide_conv_supported(g)) return POPE_ERR_ARG;
+    if (size_t(g.M + PL_BM + 2 * g.conv_wp + 2) * g.lda * 4 >= (size_t(1) << 32) || size_t(g.N + 256) * g.ldw * 4 >= (size_t(1) << 32) ||
+        size_t(g.M + PL_BM) * g.ldc * 4 >= (size_t(1) << 32) - 512 || (g.res_pl && size_t(g.M + PL_BM) * g.ldres_pl * 4 >= (size_t(1) << 32) - 512))
+        return POPE_ERR_ARG;
+    if (g.c_pl) return g.N <= 128 ? launch_conv<true, 2>(g, stream) : launch_conv<true, 4>(g, stream);
+    return g.N <= 128 ? launch_conv<false, 2>(g, stream) : launch_conv<false, 4>(g, stream);
+}
 
 // f16x3 planes -> planes (QKV, FC1 of the ViT blocks) on the 256 x 256 LDS-direct mainloop: the shapes it serves
 bool pope_wide_x3_supported(const GemmParams& g) {

@@ -596,6 +596,7 @@ int pope_launch_planes16(const GemmParams& g, hipStream_t stream) {
         case EPI_CONV:
             if (g.conv_cch > 0) {
                 if (g.K != 9 * 32 * g.conv_cch || g.lda != 32 * g.conv_cch || g.conv_wp < 3) return POPE_ERR_ARG;
+                if (pope_wide_conv_supported(g)) return pope_launch_wide_conv(g, stream);   // 256-row LDS-direct tiles, same bits
                 return out_planes ? launch16<EPI_CONV, true, true>(g, stream) : launch16<EPI_CONV, false, true>(g, stream);
             }
             return out_planes ? launch16<EPI_CONV, true>(g, stream) : launch16<EPI_CONV, false>(g, stream);

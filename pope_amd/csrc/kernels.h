@@ -108,6 +108,8 @@ int pope_launch_stream384(const GemmParams& g, hipStream_t stream);
 // same results as pope_launch_planes16 on them
 bool pope_wide_x3_supported(const GemmParams& g);   // the same mainloop on f16x3 planes -> planes (BIAS, BIAS_GELU) at large M
 int pope_launch_wide_x3(const GemmParams& g, hipStream_t stream);
+bool pope_wide_conv_supported(const GemmParams& g);  // the implicit 3 x 3 convolutions (EPI_CONV, conv_cch > 0) at large M
+int pope_launch_wide_conv(const GemmParams& g, hipStream_t stream);
 bool pope_plain256_supported(const GemmParams& g);
 int pope_launch_plain256(const GemmParams& g, hipStream_t stream);
 // the v_mfma_f32_16x16x32_f16 mainloop (gemm_planes.hip) behind both of the above; arguments already validated

@@ -351,6 +351,24 @@ def test_hip_backbone_is_deterministic_and_batch_invariant(dev, msd):
     assert torch.equal(a[0][1:2], d[0]) and torch.equal(a[1][1:2], d[1])
 
 
+def test_hip_backbone_is_batch_invariant_across_the_conv_kernels(dev, msd):
+    """At batch size (>= 4 x CUs tiles of 256 rows: 48 images of 256^2 at the 1/2-resolution layers) the implicit 3 x 3
+    convolutions run on the 256-row LDS-direct tiles of gemm_plain.hip (round 4), smaller calls on the 128 x 128 tile kernel.
+    Same K order, same accumulation order, same epilogue arithmetic: an image must come out bit-identical inside the big batch
+    and in a batch of six (the drivers' size), with the oracle parity of the small-batch path carried over by equality."""
+    from pope_amd import synth
+    b = _backbone(dev, msd)
+    x = synth.synthetic_gray_pairs(24, 256, 256, seed=31)
+    x = torch.cat([x[0], x[1]]).to(dev)          # 48 images
+    with torch.no_grad():
+        big_c, big_f = b(x)
+        for lo in (0, 18, 42):
+            sc, sf = b(x[lo:lo + 6])
+            assert torch.equal(sc, big_c[lo:lo + 6]), lo
+            assert torch.equal(sf, big_f[lo:lo + 6]), lo
+    assert bool(torch.isfinite(big_f).all())
+
+
 def test_hip_backbone_range_guard_reruns_in_fp32(dev, msd):
     from oracle import loftr_ref
     from pope_amd import synth
