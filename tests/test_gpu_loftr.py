@@ -352,20 +352,21 @@ def test_hip_backbone_is_deterministic_and_batch_invariant(dev, msd):
 
 
 def test_hip_backbone_is_batch_invariant_across_the_conv_kernels(dev, msd):
-    """At batch size (>= 4 x CUs tiles of 256 rows: 48 images of 256^2 at the 1/2-resolution layers) the implicit 3 x 3
-    convolutions run on the 256-row LDS-direct tiles of gemm_plain.hip (round 4), smaller calls on the 128 x 128 tile kernel.
-    Same K order, same accumulation order, same epilogue arithmetic: an image must come out bit-identical inside the big batch
-    and in a batch of six (the drivers' size), with the oracle parity of the small-batch path carried over by equality."""
+    """From one round of the CUs in 256-row tiles (6 images of 256^2 at the 1/2-resolution layers, 48 images at 1/4 too) the
+    implicit 3 x 3 convolutions run on the LDS-direct tiles of gemm_plain.hip (round 4), smaller calls on the 128 x 128 tile
+    kernel.  Same K order, same accumulation order, same epilogue arithmetic: an image must come out bit-identical inside the
+    big batch, in a batch of six (the drivers' size: new kernel at 1/2 resolution only) and in a batch of two (tile kernel
+    everywhere), with the oracle parity of the small-batch path carried over by equality."""
     from pope_amd import synth
     b = _backbone(dev, msd)
     x = synth.synthetic_gray_pairs(24, 256, 256, seed=31)
     x = torch.cat([x[0], x[1]]).to(dev)          # 48 images
     with torch.no_grad():
         big_c, big_f = b(x)
-        for lo in (0, 18, 42):
-            sc, sf = b(x[lo:lo + 6])
-            assert torch.equal(sc, big_c[lo:lo + 6]), lo
-            assert torch.equal(sf, big_f[lo:lo + 6]), lo
+        for lo, n in ((0, 6), (18, 2), (42, 6), (46, 2)):
+            sc, sf = b(x[lo:lo + n])
+            assert torch.equal(sc, big_c[lo:lo + n]), (lo, n)
+            assert torch.equal(sf, big_f[lo:lo + n]), (lo, n)
     assert bool(torch.isfinite(big_f).all())
 
 
