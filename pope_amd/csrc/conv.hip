@@ -229,7 +229,7 @@ int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
     if (f32 && hipMemsetAsync(q.ws, 0, pope_resnetfpn_workspace(q.n, q.H, q.W), stream) != hipSuccess) return POPE_ERR_LAUNCH;
     // generic GEMM over pixel rows: out[rows, N] = act(A[rows, K] . W^T + bias)
     auto gemm = [&](const void* a, int K, int wi, int N, int level, void* out_pl, float* out_f32, int out_pitch, float slope,
-                    const void* res_pl, int res_pitch, bool conv, int a_pitch) -> int {
+                    const void* res_pl, int res_pitch, bool conv, int a_pitch, const float* up_src = nullptr, int up_lds = 0) -> int {
         GemmParams g = {};
         const int Wp = p.Wp[level];
         const size_t shift = conv ? size_t(Wp) + 1 : 0;   // output (and shortcut) rows start at pixel Wp + 1
@@ -253,6 +253,14 @@ int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
         else g.C = out_f32 + shift * out_pitch;
         if (res_pl) { g.res_pl = static_cast<const char*>(res_pl) + shift * res_pitch * 4; g.ldres_pl = res_pitch; }
         if (conv) { g.conv_cch = a_pitch / 32; g.conv_wp = Wp; }
+        if (up_src) {
+            g.up_src = up_src; g.up_lds = up_lds; g.up_hp = p.Hp[level]; g.up_wp = Wp; g.up_n = q.n;
+            const int H = g.up_hp - 2, W = g.up_wp - 2, Hs = H / 2, Ws = W / 2;
+            g.up_sh = H > 1 ? float(Hs - 1) / float(H - 1) : 0.f;   // torch's area_pixel_compute_scale for align_corners
+            g.up_sw = W > 1 ? float(Ws - 1) / float(W - 1) : 0.f;
+            g.up_m_hw = unsigned((1ull << 32) / (unsigned long long)(g.up_hp) / (unsigned long long)(g.up_wp));
+            g.up_m_w = unsigned((1ull << 32) / (unsigned long long)(g.up_wp));
+        }
         g.range_flag = q.range_flag; g.range_bit = POPE_RANGE_INPUT;
         g.nbatch = 1;
         return pope_launch_planes16(g, stream);
@@ -312,6 +320,13 @@ int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
     if ((rc = block_s1(P3B, P3A, P3C, 13, 256, 3))) return rc;            // x3 = P3C
     // FPN (resnet_fpn.py:107-117)
     if ((rc = gemm(buf[P3C], 256, 15, 256, 3, nullptr, q.out_c, 256, 1.f, nullptr, 0, false, 256))) return rc;             // x3_out
+    // f16x3: the lateral 1 x 1 convolution's epilogue adds the bilinear x2 sample of the coarser map and writes the merged planes
+    // (round 4: the fp32 lateral map and the upsample_add pass are gone — 1.9 GB of the call's fabric traffic at 48 images); the
+    // fp32 mode keeps the two-step form
+    if (!f32) {
+        if ((rc = gemm(buf[P2C], 224, 16, 256, 2, buf[T2A], nullptr, 256, 1.f, nullptr, 0, false, 224, q.out_c, 256))) return rc;
+        if ((rc = zero_border(buf[T2A], 2, 256))) return rc;
+    } else {
     if ((rc = gemm(buf[P2C], 224, 16, 256, 2, nullptr, reinterpret_cast<float*>(buf[F2]), 256, 1.f, nullptr, 0, false, 224))) return rc;
     {
         const long long total = (long long)q.n * (p.Hp[2] - 2) * (p.Wp[2] - 2) * (256 / 4);
@@ -322,8 +337,13 @@ int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
         if ((rc = pope_check_launch())) return rc;
         if ((rc = zero_border(buf[T2A], 2, 256))) return rc;
     }
+    }
     if ((rc = conv3(T2A, 17, 256, 2, T2B, 0.01f, -1))) return rc;
     if ((rc = gemm(buf[T2B], 9 * 256, 18, 196, 2, nullptr, reinterpret_cast<float*>(buf[X2O]), 224, 1.f, nullptr, 0, true, 256))) return rc;
+    if (!f32) {
+        if ((rc = gemm(buf[P1B], 128, 19, 196, 1, buf[T1A], nullptr, 224, 1.f, nullptr, 0, false, 128, reinterpret_cast<const float*>(buf[X2O]), 224))) return rc;
+        if ((rc = zero_border(buf[T1A], 1, 224))) return rc;
+    } else {
     if ((rc = gemm(buf[P1B], 128, 19, 196, 1, nullptr, reinterpret_cast<float*>(buf[F1]), 224, 1.f, nullptr, 0, false, 128))) return rc;
     {
         const long long total = (long long)q.n * (p.Hp[1] - 2) * (p.Wp[1] - 2) * (224 / 4);
@@ -335,6 +355,7 @@ int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
                                 p.Hp[1], p.Wp[1], q.range_flag);
         if ((rc = pope_check_launch())) return rc;
         if ((rc = zero_border(buf[T1A], 1, 224))) return rc;
+    }
     }
     if ((rc = conv3(T1A, 20, 196, 1, T1B, 0.01f, -1))) return rc;
     return gemm(buf[T1B], 9 * 224, 21, 128, 1, nullptr, q.out_f, 128, 1.f, nullptr, 0, true, 224);                         // x1_out

@@ -177,6 +177,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
     const __amdgpu_buffer_rsrc_t rresp = __builtin_amdgcn_make_buffer_rsrc(   // EPI_CONV: residual as activation planes
         const_cast<void*>(EPI == EPI_CONV ? g.res_pl : nullptr), 0,
         EPI == EPI_CONV && g.res_pl ? unsigned(g.M) * unsigned(g.ldres_pl) * 4u : 0u, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rup = __builtin_amdgcn_make_buffer_rsrc(   // EPI_CONV: the FPN merge's half-resolution map
+        const_cast<float*>(EPI == EPI_CONV_UP ? g.up_src : nullptr), 0,
+        EPI == EPI_CONV_UP ? unsigned(g.up_n) * unsigned((g.up_hp - 2) / 2 + 2) * unsigned((g.up_wp - 2) / 2 + 2) * unsigned(g.up_lds) * 4u : 0u,
+        0x00020000);
     const int ec4 = (lane & 15) * 4, elr = lane >> 4;   // row-layout coordinates after the LDS transposition
     constexpr unsigned DROP = 0xFFFFFF00u;              // beyond every buffer extent: the access is discarded
 
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
         const bool col_ok = col < g.N;
         // EPI_CONV planes rows are wider than N when the channel count is not a multiple of 32 (196 -> 224): the
         // padding columns are the next convolution's K range and must read as zeros
-        const bool col_pad = EPI == EPI_CONV && OUT_PLANES && !col_ok && col < g.ldc;
+        const bool col_pad = (EPI == EPI_CONV || EPI == EPI_CONV_UP) && OUT_PLANES && !col_ok && col < g.ldc;
         const int colc = col_ok ? col : 0;
         f32x4 bias = {0.f, 0.f, 0.f, 0.f}, gamma = {0.f, 0.f, 0.f, 0.f};
         if (g.bias) bias = *reinterpret_cast<const f32x4*>(g.bias + colc);
@@ -395,9 +399,52 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
                     for (int e = 0; e < 4; ++e) res[i][e] = (float(rh[e]) + float(rl[e])) * (1.0f / A_SCALE);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
+            // EPI_CONV_UP — FPN merge: the bilinear x2 (align_corners) sample of the half-resolution map at each row's pixel.  Pixel of
+            // the pass's first row by multiply-high with host-made reciprocals + one correction (a device-side `/` keeps its
+            // reciprocal in VGPRs across the K loop), of the following rows (+ 4 each) by carries.
+            [[maybe_unused]] unsigned pb = 0, pyp = 0, pxp = 0;
+            if constexpr (EPI == EPI_CONV_UP) {
+                const unsigned hpwp = unsigned(g.up_hp) * unsigned(g.up_wp);
+                pb = __umulhi(row0, g.up_m_hw);
+                unsigned prem = row0 - pb * hpwp;
+                if (prem >= hpwp) { ++pb; prem -= hpwp; }
+                pyp = __umulhi(prem, g.up_m_w);
+                pxp = prem - pyp * unsigned(g.up_wp);
+                if (pxp >= unsigned(g.up_wp)) { ++pyp; pxp -= unsigned(g.up_wp); }
+            }
+            [[maybe_unused]] auto up_rows = [&](int i_lo, int i_hi) __attribute__((always_inline)) {
+                const int Hp = g.up_hp, Wp = g.up_wp, H = Hp - 2, W = Wp - 2, Hs = H / 2, Ws = W / 2, Wsp = Ws + 2, Hsp = Hs + 2;
+                const float sh = g.up_sh, sw = g.up_sw;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+                for (int i = i_lo; i < i_hi; ++i) {
+                    const bool inside = col_ok && row0 + 4 * i < unsigned(g.M) && pyp >= 1u && pyp <= unsigned(H) && pxp >= 1u && pxp <= unsigned(W);
+                    const int y = inside ? int(pyp) - 1 : 0, x = inside ? int(pxp) - 1 : 0;
+                    const float ry = sh * float(y), rx = sw * float(x);
+                    const int y0 = int(ry), x0 = int(rx);
+                    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+                    const float ly1 = ry - float(y0), lx1 = rx - float(x0), ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+                    const unsigned base = (pb * unsigned(Hsp) + 1u) * unsigned(Wsp) + 1u;
+                    auto at = [&](int yy, int xx) {
+                        const unsigned o = ((base + unsigned(yy) * unsigned(Wsp) + unsigned(xx)) * unsigned(g.up_lds) + unsigned(col)) * 4u;
+                        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rup, inside ? o : DROP, 0, 0));
+                    };
+                    const f32x4 v00 = at(y0, x0), v01 = at(y0, x1), v10 = at(y1, x0), v11 = at(y1, x1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)   // conv.hip:upsample_add_planes_kernel's expression, term for term
+                        res[i][e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
+                    pxp += 4u;                                        // Wp >= 10: at most one carry each
+                    const bool cx = pxp >= unsigned(Wp);
+                    pxp -= cx ? unsigned(Wp) : 0u;
+                    pyp += cx ? 1u : 0u;
+                    const bool cy = pyp >= unsigned(Hp);
+                    pyp -= cy ? unsigned(Hp) : 0u;
+                    pb += cy ? 1u : 0u;
+                }
+            };
+            __builtin_amdgcn_wave_barrier();
+            auto store_rows = [&](int i_lo, int i_hi) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = i_lo; i < i_hi; ++i) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(&E[(elr + 4 * i) * EPI_ST + ec4]);
                 const unsigned off = (row0 + 4 * i) * c_row_bytes;
                 if constexpr (EPI == EPI_BIAS) {
@@ -429,7 +476,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
                     v = v * inv + bias;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(v[e], 0.f);
-                } else if constexpr (EPI == EPI_CONV) {
+                } else if constexpr (EPI == EPI_CONV || EPI == EPI_CONV_UP) {
                     v = (v * inv + bias) + res[i];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(v[e], 0.f) + g.act_slope * __builtin_fminf(v[e], 0.f);
@@ -444,7 +491,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
                     f16x4 hi, lo;
                     pope_amax4x2(amax, v);
                     pope_split4(v * A_SCALE, hi, lo);
-                    if constexpr (EPI == EPI_CONV) {
+                    if constexpr (EPI == EPI_CONV || EPI == EPI_CONV_UP) {
                         if (col_pad) { hi = f16x4{0, 0, 0, 0}; lo = f16x4{0, 0, 0, 0}; }
                     }
                     // planes row: per 32-column chunk [32 hi | 32 lo] halves
@@ -458,6 +505,15 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_planes16_kernel(const GemmPar
                                                            col_ok ? off + unsigned(col) * 4u : DROP, 0,
                                                            EPI == EPI_BIAS_LS_RES ? 0 : 2);
                 }
+            }
+            };
+            if constexpr (EPI == EPI_CONV_UP) {   // four rows at a time: the persistent mainloop keeps two K-steps of staging registers
+                up_rows(0, 4);                    // alive across the epilogue, and 8 rows of neighbours on top of them spill those
+                store_rows(0, 4);
+                up_rows(4, 8);
+                store_rows(4, 8);
+            } else {
+                store_rows(0, 8);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -599,6 +655,7 @@ int pope_launch_planes16(const GemmParams& g, hipStream_t stream) {
                 if (pope_wide_conv_supported(g)) return pope_launch_wide_conv(g, stream);   // 256-row LDS-direct tiles, same bits
                 return out_planes ? launch16<EPI_CONV, true, true>(g, stream) : launch16<EPI_CONV, false, true>(g, stream);
             }
+            if (g.up_src) return out_planes && !g.res_pl ? launch16<EPI_CONV_UP, true>(g, stream) : POPE_ERR_ARG;
             return out_planes ? launch16<EPI_CONV, true>(g, stream) : launch16<EPI_CONV, false>(g, stream);
     }
     return POPE_ERR_ARG;

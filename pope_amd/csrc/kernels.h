@@ -14,6 +14,7 @@ enum GemmEpilogue {
     EPI_SAM_QKV = 7,      // SAM block's QKV projection written straight into the attention operand planes (sam.hip; gemm_planes.hip only)
     EPI_QKV_F16 = 8,      // plain f16 only (POPE_PREC_F16 ViT blocks): C = (A.W^T + bias) * (col < sam_dim ? sam_qscale : 1) -> f16 row-major
                           // [M, N] with NO activation scale: the operand of attention_f16.hip (q carries head_dim^-0.5 * log2 e before its ONE rounding)
+    EPI_CONV_UP = 9,      // kernel-side instantiation of EPI_CONV with GemmParams::up_src (callers pass EPI_CONV)
     EPI_CONV = 6,         // C = act(A.W^T + bias [+ res_pl]), act(v) = max(v, 0) + act_slope * min(v, 0): ReLU (0), LeakyReLU
                           // (0.01) or identity (1); the ResNet-FPN convolutions (conv.hip; gemm_planes.hip only)
 };
@@ -74,6 +75,15 @@ struct GemmParams {
     int ldres_pl;
     float act_slope;
     int conv_cch, conv_wp;
+    // EPI_CONV with up_src (gemm_planes.hip; round 4): the FPN merge of resnet_fpn.py:109-115 in the lateral 1 x 1 convolution's
+    // epilogue — output row R is pixel R of this level's zero-bordered grid [up_n, up_hp, up_wp]; the bilinear x2
+    // (align_corners) sample of the half-resolution fp32 map up_src [up_n, (up_hp - 2) / 2 + 2, (up_wp - 2) / 2 + 2, up_lds] at
+    // that pixel is added before the activation.  Replaces conv.hip's upsample_add pass (same arithmetic, same bits) and the
+    // fp32 round trip of the lateral map.  Not together with res_pl.
+    const float* up_src;
+    int up_lds, up_hp, up_wp, up_n;
+    float up_sh, up_sw;          // bilinear scales (Hs - 1) / (H - 1), (Ws - 1) / (W - 1) (0 for a single output row / column)
+    unsigned up_m_hw, up_m_w;    // floor(2^32 / (up_hp * up_wp)), floor(2^32 / up_wp)
     // plain != 0 (gemm_planes.hip only): single-product f16 arithmetic.  a_pl / w_pl (and c_pl) are f16 ROW-MAJOR tensors
     // (value * scale); K, lda, ldw and a planes output's ldc are given in 64-bit column PAIRS (= real columns / 2, so
     // that a row's pitch is still ld * 4 bytes); N, ldc of an fp32 output, bias, gamma and res stay in real columns.
