@@ -290,13 +290,38 @@ int pope_launch_resnetfpn(const ResnetFpnParams& q, hipStream_t stream) {
         return r ? r : conv3(t, w0 + 1, N, level, y, 0.f, x);
     };
     // BasicBlock with stride 2: x (level L) -> gathered taps -> t; shortcut 1x1 stride 2 -> s; y = relu(conv2(t) + s)
+    // stride-2 convolution of x (level_in) -> out (level_in + 1) straight from x's planes (gemm_plain.hip, CONV = 2) where the call
+    // fills a round of the CUs; returns 1 when the shape is not served (the caller gathers the taps instead: the same bits)
+    auto conv_s2_implicit = [&](Buf x, int level_in, int taps, int wi, int N, Buf out, float slope) -> int {
+        if (f32) return 1;
+        const int lo = level_in + 1;
+        GemmParams g = {};
+        g.a_pl = buf[x]; g.w_pl = q.w[wi]; g.bias = q.b[wi];
+        g.lda = kBufs[x].pitch; g.ldw = taps * kBufs[x].pitch; g.ldc = kBufs[out].pitch;
+        g.M = int(p.rows[lo]); g.N = N; g.K = taps * kBufs[x].pitch;
+        g.epilogue = EPI_CONV; g.act_slope = slope; g.c_pl = buf[out];
+        g.conv_cch = kBufs[x].pitch / 32; g.conv_wp = p.Wp[level_in];
+        g.conv_s2_taps = taps; g.conv_s2_hpi = p.Hp[level_in]; g.conv_s2_hpo = p.Hp[lo]; g.conv_s2_wpo = p.Wp[lo];
+        g.conv_s2_in_rows = int(p.rows[level_in]);
+        g.range_flag = q.range_flag; g.range_bit = POPE_RANGE_INPUT; g.nbatch = 1;
+        if (!pope_wide_conv_s2_supported(g)) return 1;
+        const int r = pope_launch_wide_conv_s2(g, stream);
+        return r ? r : 0;
+    };
     auto block_s2 = [&](Buf x, int level_in, Buf g9, Buf g1, Buf t, Buf s, Buf y, int w0, int N) -> int {
         const int lo = level_in + 1;
-        int r = gather(x, level_in, g9, 9);
-        if (!r) r = gemm(buf[g9], kBufs[g9].pitch, w0, N, lo, buf[t], nullptr, kBufs[t].pitch, 0.f, nullptr, 0, false, kBufs[g9].pitch);
+        int r = conv_s2_implicit(x, level_in, 9, w0, N, t, 0.f);
+        if (r == 1) {
+            r = gather(x, level_in, g9, 9);
+            if (!r) r = gemm(buf[g9], kBufs[g9].pitch, w0, N, lo, buf[t], nullptr, kBufs[t].pitch, 0.f, nullptr, 0, false, kBufs[g9].pitch);
+        }
         if (!r) r = zero_border(buf[t], lo, kBufs[t].pitch);
-        if (!r) r = gather(x, level_in, g1, 1);
-        if (!r) r = gemm(buf[g1], kBufs[g1].pitch, w0 + 2, N, lo, buf[s], nullptr, kBufs[s].pitch, 1.f, nullptr, 0, false, kBufs[g1].pitch);
+        if (r) return r;
+        r = conv_s2_implicit(x, level_in, 1, w0 + 2, N, s, 1.f);
+        if (r == 1) {
+            r = gather(x, level_in, g1, 1);
+            if (!r) r = gemm(buf[g1], kBufs[g1].pitch, w0 + 2, N, lo, buf[s], nullptr, kBufs[s].pitch, 1.f, nullptr, 0, false, kBufs[g1].pitch);
+        }
         return r ? r : conv3(t, w0 + 1, N, lo, y, 0.f, s);
     };
 

@@ -70,7 +70,12 @@ __device__ __forceinline__ f32x2 pl_gelu_pair(f32x2 x) {
 // CONV (with X3, EPI_CONV; round 4): the implicit 3 x 3 stride-1 convolution of conv.hip — K-step (chunk, tap) reads the A rows
 // shifted by (dy * Wp + dx) rows, a scalar offset of the staging instructions; chunk-major K order and W's own K offset as in
 // gemm_planes.hip (DESIGN.md findings 19, 27)
-template <int EPI, bool OUT_F16, int NWN, bool X3 = false, bool CONV = false>
+// CONV = 2: the stride-2 convolutions (3 x 3 pad 1, or the 1 x 1 shortcut: conv_s2_taps = 9 / 1) WITHOUT conv.hip's gathered tap tensor
+// (1.9 GB written and read back per 48-image call): output row R is pixel (b, yo, xo) of the zero-bordered OUTPUT grid, its taps are
+// the input rows base(R) + ky * Wpi + kx with base(R) = (b * Hpi + 2 (yo - 1)) * Wpi + 2 (xo - 1) — a per-lane row base (computed
+// once per workgroup: one tile each) plus the same scalar tap shift.  K order TAP-major, the gathered GEMM's, so that the two
+// routes give the same bits (border rows differ — the gather writes zeros there — and are zeroed by zero_border either way).
+template <int EPI, bool OUT_F16, int NWN, bool X3 = false, int CONV = 0>
 __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmParams g) {
     constexpr int BN = 64 * NWN, SUB = NWN / 2, ROWS = PL_BM + BN, NST = pl_stages(BN);
     constexpr int STAGE = ROWS * 64;   // halves per stage: 128-byte rows, A rows then W rows
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
     const int pid_n = in_group / gm, pid_m = first_m + in_group - pid_n * gm;
     const int m0 = pid_m * PL_BM, n0 = pid_n * BN;
     const unsigned lda4 = unsigned(g.lda) * 4u, ldw4 = unsigned(g.ldw) * 4u;
-    const unsigned a_rows = CONV ? unsigned(g.M) + 2u * unsigned(g.conv_wp) + 2u : unsigned(g.M);
+    const unsigned a_rows = CONV == 1 ? unsigned(g.M) + 2u * unsigned(g.conv_wp) + 2u : CONV == 2 ? unsigned(g.conv_s2_in_rows) : unsigned(g.M);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.a_pl), 0, a_rows * lda4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.w_pl), 0, unsigned(g.N) * ldw4, 0x00020000);
     const int nk = g.K / 32;   // K counts 64-bit column pairs (GemmParams::plain): a K-step = 32 pairs = 64 columns = 128 B per row
@@ -111,7 +116,15 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
     const int r8 = lane >> 3, piece = (lane & 7) ^ r8;
     unsigned va[4], vw[4];   // (vw[NIW]: an array bound from the local constexpr makes this hipcc's host pass drop the kernel silently)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) va[i] = unsigned(m0 + 32 * wave + 8 * i + r8) * lda4 + unsigned(piece) * 16u;
+    for (int i = 0; i < 4; ++i) {
+        unsigned arow = unsigned(m0 + 32 * wave + 8 * i + r8);
+        if constexpr (CONV == 2) {   // output pixel -> input base row (rows past M: beyond the input too, or harmless garbage that is dropped)
+            const unsigned hw = unsigned(g.conv_s2_hpo) * unsigned(g.conv_s2_wpo);
+            const unsigned b = arow / hw, rem = arow - b * hw, yo = rem / unsigned(g.conv_s2_wpo), xo = rem - yo * unsigned(g.conv_s2_wpo);
+            arow = (b * unsigned(g.conv_s2_hpi) + 2u * yo - 2u) * unsigned(g.conv_wp) + 2u * xo - 2u;   // (border rows wrap around: range-checked zeros)
+        }
+        va[i] = arow * lda4 + unsigned(piece) * 16u;
+    }
 #pragma unroll
     for (int i = 0; i < NIW; ++i) vw[i] = unsigned(n0 + (BN / 8) * wave + 8 * i + r8) * ldw4 + unsigned(piece) * 16u;
 // (f16x3 planes mode: the activation rows are loaded sc0 nt — FC1 fabric traffic 900 -> 808 MB per launch = 1.07 x algorithmic,
@@ -120,15 +133,19 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
     do {                                                                                                                         \
         _Float16* S_ = lds + (stage) * STAGE;                                                                                    \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                         \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (pl_lds_ptr)(S_ + (32 * wave + 8 * i_) * 64), 16, va[i_], (aoff), 0, X3 && !CONV ? 3 : 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (pl_lds_ptr)(S_ + (32 * wave + 8 * i_) * 64), 16, va[i_], (aoff), 0, X3 && CONV == 0 ? 3 : 0); \
         _Pragma("unroll") for (int i_ = 0; i_ < NIW; ++i_)                                                                       \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (pl_lds_ptr)(S_ + (PL_BM + (BN / 8) * wave + 8 * i_) * 64), 16, vw[i_], (woff), 0, 0); \
     } while (0)
     // K-step k: plain / planes GEMM: both operands at k * 128 bytes; CONV: chunk = k / 9, tap = k % 9 = (dy, dx)
     auto stage_kstep = [&](int stage, int k) {
-        if constexpr (CONV) {
+        if constexpr (CONV == 1) {
             const int chunk = k / 9, tap = k - 9 * chunk, dy = tap / 3, dx = tap - 3 * dy;
             PL_DMA2(stage, unsigned(dy * g.conv_wp + dx) * lda4 + unsigned(chunk) * 128u, unsigned(tap * g.conv_cch + chunk) * 128u);
+        } else if constexpr (CONV == 2) {   // tap-major: k = tap * cch + chunk; the 1 x 1 shortcut's only tap is the centre
+            const int tap = k / g.conv_cch, chunk = k - tap * g.conv_cch;
+            const int ky = g.conv_s2_taps == 9 ? tap / 3 : 1, kx = g.conv_s2_taps == 9 ? tap - 3 * (tap / 3) : 1;
+            PL_DMA2(stage, unsigned(ky * g.conv_wp + kx) * lda4 + unsigned(chunk) * 128u, unsigned(k) * 128u);
         } else {
             PL_DMA2(stage, k * 128, k * 128);
         }
@@ -401,17 +418,34 @@ int launch_x3(const GemmParams& g, hipStream_t stream) {
     return pope_check_launch();
 }
 
-template <bool OUT_PL, int NWN>
+template <bool OUT_PL, int NWN, int CONV = 1>
 int launch_conv(const GemmParams& g, hipStream_t stream) {
     constexpr int BN = 64 * NWN;
     static pope_dev_mask lds_ok{0};  // per kernel instantiation, per device
-    if (!pope_opt_in_lds(gemm_plain256_kernel<EPI_CONV, OUT_PL, NWN, true, true>, pl_lds_bytes(BN), lds_ok)) return POPE_ERR_LAUNCH;
+    if (!pope_opt_in_lds(gemm_plain256_kernel<EPI_CONV, OUT_PL, NWN, true, CONV>, pl_lds_bytes(BN), lds_ok)) return POPE_ERR_LAUNCH;
     const int tiles = ((g.M + PL_BM - 1) / PL_BM) * ((g.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_plain256_kernel<EPI_CONV, OUT_PL, NWN, true, true>), dim3(tiles), dim3(PL_THREADS), pl_lds_bytes(BN), stream, g);
+    hipLaunchKernelGGL((gemm_plain256_kernel<EPI_CONV, OUT_PL, NWN, true, CONV>), dim3(tiles), dim3(PL_THREADS), pl_lds_bytes(BN), stream, g);
     return pope_check_launch();
 }
 
 }  // namespace
+
+// the stride-2 convolutions of the LoFTR CNN without the gathered tap tensor (planes out, N <= 256): from one round of the CUs
+bool pope_wide_conv_s2_supported(const GemmParams& g) {
+    if (g.plain || !g.a_pl || !g.w_pl || !g.c_pl || g.epilogue != EPI_CONV || g.conv_cch <= 0 || g.nbatch > 1 || g.res_pl) return false;
+    if ((g.conv_s2_taps != 9 && g.conv_s2_taps != 1) || g.K != g.conv_s2_taps * 32 * g.conv_cch || g.lda != 32 * g.conv_cch || g.conv_wp < 4) return false;
+    if (g.conv_s2_hpo < 3 || g.conv_s2_wpo < 3 || g.conv_s2_hpi < 4 || g.conv_s2_in_rows <= 0 || (g.ldw & 31) || (g.ldc & 31) || g.N > 256) return false;
+    if (size_t(g.conv_s2_in_rows) * g.lda * 4 >= (size_t(1) << 32) || size_t(g.N + 256) * g.ldw * 4 >= (size_t(1) << 32) ||
+        size_t(g.M + PL_BM) * g.ldc * 4 >= (size_t(1) << 32) - 512)
+        return false;
+    const int bn = g.N <= 128 ? 128 : 256;
+    return size_t((g.M + PL_BM - 1) / PL_BM) * ((g.N + bn - 1) / bn) >= size_t(pope_cu_count());
+}
+
+int pope_launch_wide_conv_s2(const GemmParams& g, hipStream_t stream) {
+    if (!pope_wide_conv_s2_supported(g)) return POPE_ERR_ARG;
+    return g.N <= 128 ? launch_conv<true, 2, 2>(g, stream) : launch_conv<true, 4, 2>(g, stream);
+}
 
 // the implicit 3 x 3 convolutions of the LoFTR CNN (conv.hip) at batch size: 256-row tiles, 128 (N <= 128) or 256 columns
 bool pope_wide_conv_supported(const GemmParams& g) {

@@ -75,6 +75,10 @@ struct GemmParams {
     int ldres_pl;
     float act_slope;
     int conv_cch, conv_wp;
+    // gemm_plain.hip CONV = 2 (pope_launch_wide_conv_s2): stride-2 convolution read straight from the zero-bordered INPUT tensor
+    // [n, conv_s2_hpi, conv_wp, 32 * conv_cch] (conv_s2_in_rows pixel rows) for the output grid [n, conv_s2_hpo, conv_s2_wpo];
+    // conv_s2_taps = 9 (3 x 3, pad 1) or 1 (the 1 x 1 shortcut)
+    int conv_s2_taps, conv_s2_hpi, conv_s2_hpo, conv_s2_wpo, conv_s2_in_rows;
     // EPI_CONV with up_src (gemm_planes.hip; round 4): the FPN merge of resnet_fpn.py:109-115 in the lateral 1 x 1 convolution's
     // epilogue — output row R is pixel R of this level's zero-bordered grid [up_n, up_hp, up_wp]; the bilinear x2
     // (align_corners) sample of the half-resolution fp32 map up_src [up_n, (up_hp - 2) / 2 + 2, (up_wp - 2) / 2 + 2, up_lds] at
@@ -118,6 +122,8 @@ int pope_launch_stream384(const GemmParams& g, hipStream_t stream);
 // same results as pope_launch_planes16 on them
 bool pope_wide_x3_supported(const GemmParams& g);   // the same mainloop on f16x3 planes -> planes (BIAS, BIAS_GELU) at large M
 int pope_launch_wide_x3(const GemmParams& g, hipStream_t stream);
+bool pope_wide_conv_s2_supported(const GemmParams& g);   // stride-2 convolutions without the gathered tap tensor (large M)
+int pope_launch_wide_conv_s2(const GemmParams& g, hipStream_t stream);
 bool pope_wide_conv_supported(const GemmParams& g);  // the implicit 3 x 3 convolutions (EPI_CONV, conv_cch > 0) at large M
 int pope_launch_wide_conv(const GemmParams& g, hipStream_t stream);
 bool pope_plain256_supported(const GemmParams& g);
