@@ -158,3 +158,31 @@ def test_linemod_list_walk_is_batching_invariant(dev, sd0, golden_dir):
         part, _ = walk_pair_list(hi - lo, lambda s, e: process(lo + s, lo + e), batch=128)
         halves.append(part)
     assert torch.equal(torch.cat(halves), a)
+
+
+def test_linemod_full_list_in_eight_shards_equals_one_walk(dev, sd0, golden_dir):
+    """BASELINE config 4, the WHOLE list: all 5 796 pair ids of the LINEMOD evaluation order (fixture ids, pixels keyed by pair
+    id) walked once on one GPU in 128-pair batches, and once as the eight contiguous shards an 8-GPU job gives its ranks (run one
+    after the other here) — the per-pair match counts that the ranks would all_gather must be the single walk's, pair for pair."""
+    from pope_amd import synth
+    from pope_amd.dinov2_utils import load_dinov2_model
+    from pope_amd.pipeline import PairPipeline, load_pair_list, shard_range, walk_pair_list
+    pairs = load_pair_list(os.path.join(golden_dir, "linemod_pairs.json"))
+    n = len(pairs)
+    assert n == 5796
+    pipe = PairPipeline(load_dinov2_model(state_dict=sd0).to(dev), chunk=64)
+
+    def process(lo, hi):
+        return pipe(*synth.pairs_by_id(torch.arange(lo, hi), H, W, device=dev))["counts"]
+
+    whole, nb = walk_pair_list(n, process, batch=128)
+    assert nb == 46 and whole.shape == (n,) and int(whole.min()) > 900
+    parts, covered = [], 0
+    for rank in range(8):
+        lo, hi = shard_range(n, rank, 8)
+        assert lo == covered
+        covered = hi
+        part, _ = walk_pair_list(hi - lo, lambda s, e: process(lo + s, lo + e), batch=128)
+        parts.append(part)
+    assert covered == n and torch.equal(torch.cat(parts), whole)
+    assert pipe.model.overflow_events == 0
