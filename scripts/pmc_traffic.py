@@ -8,7 +8,7 @@ import sys
 # round 4: QKV on the 192 x 384 tile stream (mode 2 = bias -> planes), FC1 on the 256 x 256 LDS-direct tiles, proj / FC2 on the stream's
 # LayerNorm-fused mode 0 (averaged over its proj and FC2 launches)
 KERNELS = {"attention": "attn_f16x3_pipe_kernel<true, true, false>", "gemm_qkv": "gemm_rowln16_kernel<RlGeo<192, 2>, 2, false>",
-           "gemm_fc1_gelu": "gemm_plain256_kernel<1, true, 4, true>", "gemm_proj": "gemm_rowln16_kernel<RlGeo<192, 2>, 0, false>"}
+           "gemm_fc1_gelu": "gemm_plain256_kernel<1, true, 4, true, 0>", "gemm_proj": "gemm_rowln16_kernel<RlGeo<192, 2>, 0, false>"}
 src = sys.argv[1]
 blocks, cur = {}, None
 for line in open(src):
