@@ -213,11 +213,11 @@ __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g
         const_cast<float*>(g.res), 0, unsigned(RES_TABLE ? g.res_mod : g.M) * unsigned(g.ldres) * 4u, 0x00020000);
 
     // Residual prefetch.  The epilogue's bytes (residual in, x and xn out: 590 KB per 128 rows) hit HBM from all 256 CUs at
-    // once while the K loops leave it idle; the residual third of that burst is pulled forward: during the K loop every lane
-    // touches three of the tile's 12 RM residual lines (one dword each, loaded straight into an LDS landing pad that nobody
-    // reads — no register, no wait), so the epilogue's residual loads find their lines in L2 / MALL.
+    // once while the K loops leave it idle; the residual third of that burst is pulled forward: in the LAST K-steps of the tile
+    // (one round per K-step; spread over the whole K loop the first lines are 100+ us old by the epilogue: FC2 +1.7 % slower)
+    // every lane touches one of the tile's 12 RM residual lines per round (one dword, loaded straight into an LDS landing pad
+    // that nobody reads — no register, no wait), so the epilogue's residual loads find their lines in L2 / MALL.
     lds_void_ptr pf_pad = (lds_void_ptr)(reinterpret_cast<char*>(smem) + G::PF_OFF + wave * 256);
-    const int pf_step = nk / G::NPF;
     auto prefetch_res = [&](int tile_, int j) {
         int t_ = wave * 64 + pope_lane_id();
         asm volatile("" : "+v"(t_));
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g
                 wh[nxt] = *reinterpret_cast<const f16x8*>(S + w_row + (ni + 1) * 16 * ROWB + sw_hi);
             }
             if constexpr (LN && !RES_TABLE)
-                if (ni == 2 && g.rl_prefetch && pf_step > 0 && kt % pf_step == 0 && kt / pf_step < G::NPF) prefetch_res(tile, kt / pf_step);
+                if (ni == 2 && g.rl_prefetch && kt >= nk - 1 - G::NPF && kt < nk - 1 && nk > G::NPF) prefetch_res(tile, kt - (nk - 1 - G::NPF));
 #pragma unroll
             for (int mi = 0; mi < NMI; ++mi) acc[mi][ni] = mfma16(wl[cur], ah[mi], acc[mi][ni]);
 #pragma unroll
