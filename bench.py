@@ -441,6 +441,27 @@ def main():
             finally:
                 pipe.want_conf = False
                 torch.cuda.empty_cache()
+            if args.streams == 1:
+                try:   # the same step with the ViT chunks of a step spread over two HIP streams (PairPipeline(streams=2)): the chunks' tile-quantisation
+                    # tails and HBM-bound kernels overlap the other chunk's MFMA phases.  Not the headline: overlapping launches stretch every
+                    # kernel's own duration, and the headline's roofline entry is per-launch time of the dominant kernel on its stream.
+                    pipe2 = PairPipeline(model, chunk=args.chunk, streams=2, match_precision=match_precision)
+                    ref_out = pipe(img0, img1)
+                    o2 = pipe2(img0, img1)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        o2 = pipe2(img0, img1)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t1) / 3
+                    same = all(torch.equal(o2[k], ref_out[k]) for k in ("feat0", "feat1", "counts", "i_ids", "j_ids", "mconf"))
+                    result["two_streams"] = {"value": round(args.pairs / dt, 2), "unit": "image-pairs/s", "ms_per_step": round(dt * 1e3, 3), "streams": 2,
+                                             "verified": bool(same), "note": "every output bit-equal to the one-stream step's"}
+                    del pipe2, o2, ref_out
+                except Exception as e:  # noqa: BLE001
+                    result["two_streams"] = {"error": f"{type(e).__name__}: {e}"}
+                finally:
+                    torch.cuda.empty_cache()
             try:
                 ramp = bench_legs.attention_ramp_leg(device, chunk=args.chunk)
                 result["attention_ramp"] = ramp
