@@ -79,15 +79,13 @@ __device__ __forceinline__ float quad_sum(float v) {
 __device__ unsigned long long g_rl_dbg[3][64];
 #define RL_STAMP(slot)                                                                                             \
     do {                                                                                                           \
-        if (blockIdx.x == 0 && threadIdx.x == 0 && rl_si + (slot) < 64)                                            \
+        if (LN && blockIdx.x == 0 && threadIdx.x == 0 && rl_si + (slot) < 64)   /* the LayerNorm modes only */     \
             g_rl_dbg[g.K == 384 ? 0 : (g.K == 1536 ? 1 : 2)][rl_si + (slot)] = wall_clock64();                     \
     } while (0)
 #else
 #define RL_STAMP(slot) do {} while (0)
 #endif
 
-// LN_PLANES: LayerNorm output as activation planes (next GEMM's operand) or fp32 (final norm);
-// RES_TABLE: the residual row is row % res_mod of a [res_mod, 384] table (patch embed: cls / conv bias + pos)
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a full workgroup-scope fence: the compiler puts
 // s_waitcnt vmcnt(0) in front of it, i.e. every global store of the epilogue in flight must be acknowledged before the wave
 // may even arrive (2 - 3 us per tile seam, and in the middle of the epilogue between the x stores and the second moment).
@@ -127,6 +125,7 @@ __device__ __forceinline__ f32x2 rl_gelu_pair(f32x2 x) {
     return __builtin_elementwise_fma(relu, __builtin_elementwise_fma(q, f32x2{-2.f, -2.f}, f32x2{1.f, 1.f}), x * q);
 }
 
+// RES_TABLE (LayerNorm modes): the residual row is row % res_mod of a [res_mod, 384] table (patch embed: cls / conv bias + pos)
 template <class G, int MODE, bool RES_TABLE>
 __global__ __launch_bounds__(G::RTH) void gemm_rowln16_kernel(const GemmParams g, int n_tiles, int ncol) {
     constexpr bool LN = MODE == RL_LN_PLANES || MODE == RL_LN_F32, LN_PLANES = MODE == RL_LN_PLANES;
