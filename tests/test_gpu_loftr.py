@@ -351,7 +351,8 @@ def test_hip_backbone_is_deterministic_and_batch_invariant(dev, msd):
     assert torch.equal(a[0][1:2], d[0]) and torch.equal(a[1][1:2], d[1])
 
 
-def test_hip_backbone_is_batch_invariant_across_the_conv_kernels(dev, msd):
+@pytest.mark.parametrize("n,H,W", [(48, 256, 256), (40, 192, 320)])
+def test_hip_backbone_is_batch_invariant_across_the_conv_kernels(dev, msd, n, H, W):
     """From one round of the CUs in 256-row tiles (6 images of 256^2 at the 1/2-resolution layers, 48 images at 1/4 too) the
     implicit 3 x 3 convolutions run on the LDS-direct tiles of gemm_plain.hip (round 4), smaller calls on the 128 x 128 tile
     kernel.  Same K order, same accumulation order, same epilogue arithmetic: an image must come out bit-identical inside the
@@ -359,14 +360,14 @@ def test_hip_backbone_is_batch_invariant_across_the_conv_kernels(dev, msd):
     everywhere), with the oracle parity of the small-batch path carried over by equality."""
     from pope_amd import synth
     b = _backbone(dev, msd)
-    x = synth.synthetic_gray_pairs(24, 256, 256, seed=31)
-    x = torch.cat([x[0], x[1]]).to(dev)          # 48 images
+    x = synth.synthetic_gray_pairs(n // 2, H, W, seed=31)
+    x = torch.cat([x[0], x[1]]).to(dev)          # n images (the non-square case: the stride-2 loader's pixel decomposition with Hp != Wp)
     with torch.no_grad():
         big_c, big_f = b(x)
-        for lo, n in ((0, 6), (18, 2), (42, 6), (46, 2)):
-            sc, sf = b(x[lo:lo + n])
-            assert torch.equal(sc, big_c[lo:lo + n]), (lo, n)
-            assert torch.equal(sf, big_f[lo:lo + n]), (lo, n)
+        for lo, k in ((0, 6), (18, 2), (n - 6, 6), (n - 2, 2)):
+            sc, sf = b(x[lo:lo + k])
+            assert torch.equal(sc, big_c[lo:lo + k]), (lo, k)
+            assert torch.equal(sf, big_f[lo:lo + k]), (lo, k)
     assert bool(torch.isfinite(big_f).all())
 
 
