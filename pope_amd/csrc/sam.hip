@@ -27,9 +27,11 @@ namespace {
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 constexpr float L2E = 1.44269504088896340736f;
 constexpr float A_SCALE = K_PLANES_ACT_SCALE;
@@ -175,59 +177,155 @@ __global__ __launch_bounds__(256) void sam_rowmap_kernel(int* __restrict__ map, 
 }
 
 // Rh / Rw: [ws][ws][hd] fp32, the gathered tables get_rel_pos returns (image_encoder.py:288-316; host, once per model).
-// Workgroup = TPB = 256 / JT tokens of one window batch (JT = DQ - hd = 32 or 128 columns: 2 ws live ones, zeros behind).
-// q is read back from the Q' rows the QKV epilogue (and the pad-token kernel) wrote: q * scale * log2 e as hi [+ lo].
-template <int HD, bool PLAIN>
+// q.Rh[qh, 0..ws) is the same small matrix product for every token of window row qh (and q.Rw[qw, 0..ws) for every token of
+// column qw), so the columns are made on the matrix cores, one wave per (window batch, axis, line r, head group):
+//     D[j][rho] = sum_k R[r][j][k] * q[rho][k],    rho = (head, position on the line), 32 of them per MFMA column block
+// A = the line's table slice, split into f16 hi / lo (x 256) in registers once per wave; B = q from the Q' rows the QKV
+// epilogue (and the pad-token kernel) wrote (q * scale * log2 e as hi [+ lo]).  f16x3: R_lo.q_hi + R_hi.q_lo + R_hi.q_hi;
+// f16 mode: q has no lo half.  What the kernel costs is its memory pattern, not the arithmetic (scripts/sam_relpos_lab.hip,
+// profiles/r04/sam_relpos_lab.txt: 18 us of 110 without loads and stores), so
+//  * a block's 32 q rows are fetched as whole rows by neighbouring lanes (10 lanes x 16 bytes per row) one block ahead
+//    and handed to the MFMA layout through a wave-private LDS tile (no barrier: a wave's LDS operations stay in order);
+//  * lanes c and c + 32 swap half of their results so that each holds 8 consecutive j of its q row: one 16-byte store;
+//  * window blocks walk the task list XCD by XCD (`xcd_remap`): the two axes of a window read the same 0.7 MB of Q'
+//    and write the two halves of the same 56-byte segments, which then meet in one L2.
+// Rows n >= Nq and columns j >= 2 ws of Q' stay the zeros of the once-per-pass memset.
+// (Rounds 2-3 ran this on the vector ALU, one (token, j) pair per thread with the table row in registers.)
+typedef unsigned u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte store at dword alignment
+template <int HD, int MB, bool PLAIN>
 __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __restrict__ Rh, const float* __restrict__ Rw,
-                                                              _Float16* __restrict__ Qp, AttnGeom a, unsigned* range_flag) {
-    extern __shared__ __attribute__((aligned(16))) float sq[];   // [TPB][heads * HD]
-    const int JT = a.DQ - HD, TPB = 256 / JT;
-    const int tid = threadIdx.x, t = tid / JT, j = tid - t * JT;
-    const int wb = blockIdx.y, n0 = blockIdx.x * TPB;
-    for (int idx = tid; idx < TPB * a.heads * (HD / 4); idx += 256) {
-        const int tt = idx / (a.heads * (HD / 4)), rem = idx - tt * a.heads * (HD / 4);
-        const int head = rem / (HD / 4), c = (rem - head * (HD / 4)) * 4;
-        const int n = n0 + tt;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < a.Nq) {
-            const _Float16* qr = Qp + ((size_t)(wb * a.heads + head) * a.Npad + n) * (PLAIN ? a.DQ : 2 * a.DQ) + c;
-            v = __builtin_convertvector(*reinterpret_cast<const f16x4*>(qr), f32x4);
-            if constexpr (!PLAIN) v = v + __builtin_convertvector(*reinterpret_cast<const f16x4*>(qr + a.DQ), f32x4);
-        }
-        *reinterpret_cast<f32x4*>(&sq[(tt * a.heads + head) * HD + c]) = v;
-    }
-    __syncthreads();
-    const int n = n0 + t;
-    const bool live = n < a.Nq && j < 2 * a.ws;
-    f32x4 R[HD / 4];
-    if (live) {
-        const int qh = n / a.ws, qw = n - qh * a.ws;
-        const float* rp = j < a.ws ? Rh + ((size_t)qh * a.ws + j) * HD : Rw + ((size_t)qw * a.ws + (j - a.ws)) * HD;
+                                                              _Float16* __restrict__ Qp, AttnGeom a, int hpg, int n_tasks,
+                                                              unsigned ws_magic, int by_xcd, unsigned* range_flag) {
+    constexpr int KS = HD / 16, PR = HD / 8, ST = PR + 1, NT = PR / 2;   // 16-byte pieces per q row, LDS row stride, fetches per lane
+    constexpr int NP = PLAIN ? 1 : 2;
+    constexpr float W_SCALE = 256.0f;
+    __shared__ u32x4 stage_all[4][NP][32 * ST];
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    u32x4(*stage)[32 * ST] = stage_all[threadIdx.x >> 6];
+    int task = (by_xcd ? xcd_remap(blockIdx.x, gridDim.x) : int(blockIdx.x)) * 4 + (threadIdx.x >> 6);
+    if (task >= n_tasks) return;   // no barrier below
+    const int n_hg = a.heads / hpg;
+    const int hg = task % n_hg;
+    task /= n_hg;
+    const int r = task % a.ws;
+    task /= a.ws;
+    const int axis = task & 1, wb = task >> 1;
+    const int q_row = PLAIN ? a.DQ : 2 * a.DQ;
+
+    // A fragments: lane (c, h) holds R[r][j = 32 mb + c][16 s + 8 h + 0..7] * 256 as hi and lo
+    f16x8 rh[MB][KS], rl[MB][KS];
+    const float* tab = (axis ? Rw : Rh) + (size_t)r * a.ws * HD + 8 * h;
 #pragma unroll
-        for (int c = 0; c < HD / 4; ++c) R[c] = *reinterpret_cast<const f32x4*>(rp + 4 * c);
-    } else {
+    for (int mb = 0; mb < MB; ++mb) {
+        const int j = 32 * mb + c;
 #pragma unroll
-        for (int c = 0; c < HD / 4; ++c) R[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    float amax = 0.f;
-    if (n < a.Npad) {
-        for (int head = 0; head < a.heads; ++head) {
-            const float* q = &sq[(t * a.heads + head) * HD];
-            f32x2 acc2[2] = {{0.f, 0.f}, {0.f, 0.f}};   // four partial sums, two v_pk_fma_f32 per 16-byte LDS broadcast
-#pragma unroll
-            for (int c = 0; c < HD / 4; ++c) {
-                const f32x4 q4 = *reinterpret_cast<const f32x4*>(q + 4 * c);
-                acc2[0] = __builtin_elementwise_fma(f32x2{q4[0], q4[1]}, f32x2{R[c][0], R[c][1]}, acc2[0]);
-                acc2[1] = __builtin_elementwise_fma(f32x2{q4[2], q4[3]}, f32x2{R[c][2], R[c][3]}, acc2[1]);
+        for (int s = 0; s < KS; ++s) {
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+            if (j < a.ws) {
+                v0 = *reinterpret_cast<const f32x4*>(tab + (size_t)j * HD + 16 * s);
+                v1 = *reinterpret_cast<const f32x4*>(tab + (size_t)j * HD + 16 * s + 4);
             }
-            float acc = (acc2[0][0] + acc2[0][1]) + (acc2[1][0] + acc2[1][1]);
-            acc *= sqrtf(float(HD));   // q carries scale * log2 e: undo the scale
-            amax = fmaxf(amax, fabsf(acc));
-            if (!(acc == acc)) amax = INFINITY;
-            const _Float16 hi = _Float16(acc);
-            _Float16* dst = Qp + ((size_t)(wb * a.heads + head) * a.Npad + n) * (PLAIN ? a.DQ : 2 * a.DQ) + HD + j;
-            dst[0] = hi;
-            if constexpr (!PLAIN) dst[a.DQ] = _Float16(acc - float(hi));
+            f16x4 h0, l0, h1, l1;
+            pope_split4(v0 * W_SCALE, h0, l0);
+            pope_split4(v1 * W_SCALE, h1, l1);
+            rh[mb][s] = cat(h0, h1);
+            rl[mb][s] = cat(l0, l1);
+        }
+    }
+
+    const int n_rho = a.ws * hpg;
+    const size_t grp0 = (size_t)(wb * a.heads + hg * hpg) * a.Npad;
+    auto row_of = [&](int rho) -> size_t {   // Q' row of the rho-th (head, position) of this line; rho / ws by the host's reciprocal
+        const int hl = int(__umulhi(unsigned(rho), ws_magic)), i = rho - hl * a.ws;
+        return grp0 + (size_t)hl * a.Npad + (axis ? i * a.ws + r : r * a.ws + i);
+    };
+    u32x4 pf[NP][NT];
+    auto fetch = [&](int rho0) {   // piece p = lane + 64 t of the block: row p / PR, 16-byte piece p % PR
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int p = lane + 64 * t, cr = p / PR, pc = p - cr * PR;
+            const bool in = rho0 + cr < n_rho;
+            const _Float16* src = Qp + row_of(rho0 + cr) * q_row + 8 * pc;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                pf[pl][t] = u32x4{0, 0, 0, 0};
+                if (in) pf[pl][t] = *reinterpret_cast<const u32x4*>(src + pl * a.DQ);
+            }
+        }
+    };
+    const float out_scale = sqrtf(float(HD)) * (1.0f / W_SCALE);   // q carries scale * log2 e: undo the scale
+    const bool pairs = !(a.ws & 1);
+    float amax = 0.f;
+    fetch(0);
+    for (int rho0 = 0; rho0 < n_rho; rho0 += 32) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int p = lane + 64 * t, cr = p / PR, pc = p - cr * PR;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) stage[pl][cr * ST + pc] = pf[pl][t];
+        }
+        if (rho0 + 32 < n_rho) fetch(rho0 + 32);
+        f16x8 qh[KS], ql[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qh[s] = __builtin_bit_cast(f16x8, stage[0][c * ST + 2 * s + h]);
+            if constexpr (!PLAIN) ql[s] = __builtin_bit_cast(f16x8, stage[1][c * ST + 2 * s + h]);
+        }
+        const bool live = rho0 + c < n_rho;
+        _Float16* row = Qp + row_of(rho0 + c) * q_row + HD + axis * a.ws;   // this q row's relative-position columns of the axis
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc = mfma_f16(rl[mb][s], qh[s], acc);
+                if constexpr (!PLAIN) acc = mfma_f16(rh[mb][s], ql[s], acc);
+                acc = mfma_f16(rh[mb][s], qh[s], acc);
+            }
+            // lane (c, h) holds D[j = 32 mb + 8 g + 4 h + e][rho] in acc[4 g + e]
+            u32x2 gh[4], gl[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 32 * mb + 8 * g + 4 * h + e < a.ws ? acc[4 * g + e] * out_scale : 0.f;
+                amax = pope_amax4(amax, v);
+                const float s4 = (v[0] + v[1]) + (v[2] + v[3]);
+                if (!(s4 == s4)) amax = INFINITY;   // NaN (fmax drops it)
+                f16x4 hi = __builtin_convertvector(v, f16x4), lo = hi;
+                if constexpr (!PLAIN) pope_split4(v, hi, lo);
+                gh[g] = __builtin_bit_cast(u32x2, hi);
+                gl[g] = __builtin_bit_cast(u32x2, lo);
+            }
+            // lane h = 0 keeps its groups 2 p and takes the partner's (j = 16 p + 0..7), lane h = 1 the groups 2 p + 1 (j = 16 p + 8..15)
+            auto put = [&](const u32x2 (&grp)[4], int p2, _Float16* base) {
+                const u32x2 send = h ? grp[2 * p2] : grp[2 * p2 + 1];
+                const u32x2 recv = {unsigned(__shfl_xor(int(send[0]), 32)), unsigned(__shfl_xor(int(send[1]), 32))};
+                const u32x4 out = h ? u32x4{recv[0], recv[1], grp[2 * p2 + 1][0], grp[2 * p2 + 1][1]}
+                                    : u32x4{grp[2 * p2][0], grp[2 * p2][1], recv[0], recv[1]};
+                const int jb = 32 * mb + 16 * p2 + 8 * h, cnt = a.ws - jb;   // live columns among the lane's eight
+                if (!live || cnt <= 0) return;
+                _Float16* d = base + jb;
+                if (cnt >= 8 && pairs) {
+                    *reinterpret_cast<u32x4a4*>(d) = out;
+                } else if (pairs) {
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2)
+                        if (2 * w2 + 1 < cnt) *reinterpret_cast<unsigned*>(d + 2 * w2) = out[w2];
+                } else {   // odd window side: the w axis starts on an odd column
+                    const f16x8 o8 = __builtin_bit_cast(f16x8, out);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e < cnt) d[e] = o8[e];
+                }
+            };
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                put(gh, p2, row);
+                if constexpr (!PLAIN) put(gl, p2, row + a.DQ);
+            }
         }
     }
     pope_range_flag(range_flag, POPE_RANGE_QKV, !(amax < POPE_F16_OVERFLOW));
@@ -833,13 +931,22 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
                 POPE_TRY(pope_check_launch());
             }
             // ... and the relative-position columns of Q' from the Q' rows
-            const int tpb = 256 / (a.DQ - hd);
-            const dim3 rgrid((a.Npad + tpb - 1) / tpb, a.B * a.nw * a.nw);
-            const size_t lds = size_t(tpb) * dim * sizeof(float);
-#define POPE_SAM_RELPOS(HD, PL) \
-    hipLaunchKernelGGL((sam_attn_relpos_kernel<HD, PL>), rgrid, dim3(256), lds, stream, k.rel_h, k.rel_w, Qp, a, flag)
-            if (hd == 80) { if (plain) POPE_SAM_RELPOS(80, true); else POPE_SAM_RELPOS(80, false); }
-            else { if (plain) POPE_SAM_RELPOS(64, true); else POPE_SAM_RELPOS(64, false); }
+            int hpg = 256 / a.ws < 1 ? 1 : (256 / a.ws > a.heads ? a.heads : 256 / a.ws);   // heads per wave: about 256 q rows
+            while (a.heads % hpg) --hpg;
+            const long long n_tasks = (long long)a.B * a.nw * a.nw * 2 * a.ws * (a.heads / hpg);
+            if (a.ws > 64 || n_tasks > 0x7ffffff0ll) return POPE_ERR_ARG;
+            const dim3 rgrid((unsigned)((n_tasks + 3) / 4));
+            const unsigned ws_magic = unsigned(((1ull << 32) + a.ws - 1) / a.ws);   // rho / ws = umulhi(rho, magic) for rho < 2^16
+            // both axes of one window batch on one XCD while its Q' rows fit that L2 comfortably (the 28 tasks of a 14 x 14 window: yes;
+            // a 64 x 64 global block: no — measured slower, profiles/r04/sam_relpos_lab.txt)
+            const int by_xcd = size_t(a.Nq) * a.heads * (plain ? a.DQ : 2 * a.DQ) * 2 <= (1u << 20);
+#define POPE_SAM_RELPOS(HD, MB, PL)                                                                                                       \
+    hipLaunchKernelGGL((sam_attn_relpos_kernel<HD, MB, PL>), rgrid, dim3(256), 0, stream, k.rel_h, k.rel_w, Qp, a, hpg, int(n_tasks), ws_magic, \
+                       by_xcd, flag)
+#define POPE_SAM_RELPOS_MB(HD, PL) do { if (a.ws > 32) POPE_SAM_RELPOS(HD, 2, PL); else POPE_SAM_RELPOS(HD, 1, PL); } while (0)
+            if (hd == 80) { if (plain) POPE_SAM_RELPOS_MB(80, true); else POPE_SAM_RELPOS_MB(80, false); }
+            else { if (plain) POPE_SAM_RELPOS_MB(64, true); else POPE_SAM_RELPOS_MB(64, false); }
+#undef POPE_SAM_RELPOS_MB
 #undef POPE_SAM_RELPOS
             POPE_TRY(pope_check_launch());
         }
