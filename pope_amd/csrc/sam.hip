@@ -8,6 +8,8 @@
 //     K'[m] = [ k[m]       | onehot(kh(m))          | onehot(kw(m))          ]
 // so Q'.K'^T is the biased score and the flash kernel needs no bias path at all: the relative-position terms ride on
 // the matrix cores (K' one-hot columns are exact in f16 and have no lo plane: 2 MFMAs per step there instead of 3).
+// The 64 x 64 global blocks skip the widening (round 4, template flag BIAS): their 32-key tiles lie inside one key row, so the
+// two terms are a per-lane register table plus one LDS broadcast that the score accumulators start from.
 // The QKV GEMM's epilogue (gemm_planes.hip, EPI_SAM_QKV), `sam_pad_tokens_kernel` and `sam_attn_relpos_kernel` build Q', K', V
 // as f16 hi/lo planes per (window, head) — the window partition is a row map of the epilogue, and the zero-padded tokens of the bottom / right windows
 // (image_encoder.py:251-254, padded AFTER norm1) get k = v = the qkv bias, exactly what Linear(0) gives the reference.
@@ -21,6 +23,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 
 namespace {
@@ -192,10 +195,13 @@ __global__ __launch_bounds__(256) void sam_rowmap_kernel(int* __restrict__ map, 
 // Rows n >= Nq and columns j >= 2 ws of Q' stay the zeros of the once-per-pass memset.
 // (Rounds 2-3 ran this on the vector ALU, one (token, j) pair per thread with the table row in registers.)
 typedef unsigned u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte store at dword alignment
-template <int HD, int MB, bool PLAIN>
+// TAB (global blocks in bias mode, `sam_attn_kernel<.., BIAS>`): the columns go to the bias table [G Npad][relh 0..ws | relw 0..ws]
+// instead of Q' — fp32 in the f16x3 mode (the accumulators as they are), f16 in the plain-f16 mode.
+template <int HD, int MB, bool PLAIN, bool TAB>
 __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __restrict__ Rh, const float* __restrict__ Rw,
-                                                              _Float16* __restrict__ Qp, AttnGeom a, int hpg, int n_tasks,
-                                                              unsigned ws_magic, int by_xcd, unsigned* range_flag) {
+                                                              _Float16* __restrict__ Qp, void* __restrict__ bias_tab, AttnGeom a,
+                                                              int hpg, int n_tasks, unsigned ws_magic, int by_xcd,
+                                                              unsigned* range_flag) {
     constexpr int KS = HD / 16, PR = HD / 8, ST = PR + 1, NT = PR / 2;   // 16-byte pieces per q row, LDS row stride, fetches per lane
     constexpr int NP = PLAIN ? 1 : 2;
     constexpr float W_SCALE = 256.0f;
@@ -272,7 +278,9 @@ __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __res
             if constexpr (!PLAIN) ql[s] = __builtin_bit_cast(f16x8, stage[1][c * ST + 2 * s + h]);
         }
         const bool live = rho0 + c < n_rho;
-        _Float16* row = Qp + row_of(rho0 + c) * q_row + HD + axis * a.ws;   // this q row's relative-position columns of the axis
+        const size_t my_row = row_of(rho0 + c);
+        _Float16* row = Qp + my_row * q_row + HD + axis * a.ws;   // this q row's relative-position columns of the axis
+        if constexpr (TAB && PLAIN) row = static_cast<_Float16*>(bias_tab) + my_row * (2 * a.ws) + axis * a.ws;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             f32x16 acc;
@@ -285,6 +293,26 @@ __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __res
                 acc = mfma_f16(rh[mb][s], qh[s], acc);
             }
             // lane (c, h) holds D[j = 32 mb + 8 g + 4 h + e][rho] in acc[4 g + e]
+            if constexpr (TAB && !PLAIN) {   // fp32 table: the same lane swap on four floats, two 16-byte stores (ws % 8 == 0 here)
+                float* trow = static_cast<float*>(bias_tab) + my_row * (2 * a.ws) + axis * a.ws;
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    f32x4 mine[2], recv;
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) mine[q2][e] = acc[4 * (2 * p2 + q2) + e] * out_scale;
+                    const f32x4 send = h ? mine[0] : mine[1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) recv[e] = __shfl_xor(send[e], 32);
+                    const int jb = 32 * mb + 16 * p2 + 8 * h;
+                    if (live && jb + 8 <= a.ws) {
+                        *reinterpret_cast<f32x4*>(trow + jb) = h ? recv : mine[0];
+                        *reinterpret_cast<f32x4*>(trow + jb + 4) = h ? mine[1] : recv;
+                    }
+                }
+                continue;
+            }
             u32x2 gh[4], gl[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -324,7 +352,7 @@ __global__ __launch_bounds__(256) void sam_attn_relpos_kernel(const float* __res
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) {
                 put(gh, p2, row);
-                if constexpr (!PLAIN) put(gl, p2, row + a.DQ);
+                if constexpr (!PLAIN && !TAB) put(gl, p2, row + a.DQ);
             }
         }
     }
@@ -355,12 +383,21 @@ struct AttnCfg {
     static constexpr size_t LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
 
-template <int NSTEP, int HSTEP, int DVT, int WAVES, bool PLAIN>
+// BIAS (the 64 x 64 global blocks): Q' / K' carry q and k only, and the relative-position terms arrive as a bias table
+// [G Npad][relh 0..64 | relw 0..64] (`sam_attn_relpos_kernel<.., true>`; fp32, f16 in the plain-f16 mode).  A 32-key tile
+// lies inside one key row (kh = kt / 2, kw = 32 (kt & 1) + key), so the score accumulators START from
+// relw[q][kw(i)] + relh[q][kh] instead of zero: the lane's 2 x 16 relw values live in registers, relh[q][.] of the
+// workgroup's queries in LDS (one broadcast read per tile) — 5 score k-steps per tile instead of 13, K' rows of 80
+// columns instead of 208 (profiles/r04/sam_global_bias_ab.txt).
+constexpr int BIAS_WS = 64, BIAS_ST = BIAS_WS + 1;
+template <int NSTEP, int HSTEP, int DVT, int WAVES, bool PLAIN, bool BIAS>
 __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void sam_attn_kernel(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp,
-                                                         const _Float16* __restrict__ Vp, _Float16* __restrict__ out_pl,
-                                                         AttnGeom a, unsigned* range_flag) {
+                                                         const _Float16* __restrict__ Vp, const void* __restrict__ bias_tab,
+                                                         _Float16* __restrict__ out_pl, AttnGeom a, unsigned* range_flag) {
     using C = AttnCfg<NSTEP, HSTEP, DVT, WAVES, PLAIN>;
+    using BT = std::conditional_t<PLAIN, _Float16, float>;   // bias table element
     constexpr int NT = C::NT, QB = C::QB;
+    static_assert(!BIAS || NSTEP == HSTEP, "bias mode: no relative-position columns in Q' / K'");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Kh = reinterpret_cast<_Float16*>(smem);
     _Float16* Kl = Kh + KT * C::KST;
@@ -444,9 +481,29 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void sam_attn_kernel(const _
     float m_run = -INFINITY;    // running max (log2 domain)
     f32x2 l_run = {0.f, 0.f};   // running sum of the 2^10-scaled probabilities, two partial lanes
 
+    // bias mode: relh[q][0..64) of the workgroup's queries -> LDS behind the stage, the lane's relw values -> registers
+    float* Bh = smem + C::LDS_BYTES / 4;
+    float bw[BIAS ? 2 : 1][16];
+    if constexpr (BIAS) {
+        const BT* tab = static_cast<const BT*>(bias_tab) + ((size_t)grp * a.Npad + q0) * (2 * BIAS_WS);
+        for (int idx = tid; idx < QB * BIAS_WS; idx += NT) {
+            const int qq = idx / BIAS_WS, k = idx - qq * BIAS_WS;
+            Bh[qq * BIAS_ST + k] = q0 + qq < a.Npad ? float(tab[(size_t)qq * (2 * BIAS_WS) + k]) : 0.f;
+        }
+        const bool in = q0 + wave * 32 + r < a.Npad;
+        const BT* wrow = tab + (size_t)(wave * 32 + r) * (2 * BIAS_WS) + BIAS_WS + 4 * h;
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bw[par][4 * g4 + e] = in ? float(wrow[32 * par + 8 * g4 + e]) : 0.f;
+    }
+
     const int nkt = a.Npad / KT;
     load_kv(0);
-    for (int kt = 0; kt < nkt; ++kt) {
+    auto tile = [&](const int kt, auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
         if (kt) __syncthreads();   // every wave is done with the previous tile
         store_kv();
         __syncthreads();
@@ -454,8 +511,14 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void sam_attn_kernel(const _
 
         // ---- S^T = K'.Q'^T: 3 MFMAs per 16-wide step over q / k proper, 2 over the one-hot columns (no lo plane)
         f32x16 s;
+        if constexpr (BIAS) {
+            const float bh = Bh[(wave * 32 + r) * BIAS_ST + (kt >> 1)];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+            for (int i = 0; i < 16; ++i) s[i] = bw[PAR][i] + bh;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+        }
         const _Float16* kb_h = Kh + r * C::KST + 8 * h;
         const _Float16* kb_l = Kl + r * C::KLST + 8 * h;
 #pragma unroll
@@ -527,6 +590,14 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void sam_attn_kernel(const _
                 }
             }
         }
+    };
+    if constexpr (BIAS) {   // two tiles per key row: the parity selects the relw registers at compile time
+        for (int kt = 0; kt < nkt; kt += 2) {
+            tile(kt, std::integral_constant<int, 0>{});
+            tile(kt + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) tile(kt, std::integral_constant<int, 0>{});
     }
     __syncthreads();   // the stage is free: reuse it for the O^T transposition
 
@@ -711,7 +782,8 @@ __global__ __launch_bounds__(256) void sam_ln2d_kernel(const float* __restrict__
 struct AttnPlan {
     AttnGeom geom;
     int nstep;      // DQ / 16
-    size_t qp, kp, vp;   // bytes
+    bool bias;      // relative-position terms as a bias table (sam_attn_kernel<.., BIAS>), not as columns of Q' / K'
+    size_t qp, kp, vp, tab;   // bytes
 };
 
 // the smallest instantiated score depth that holds hd + 2 ws columns
@@ -724,28 +796,32 @@ bool plan_attention(int B, int g, int ws, int heads, int hd, AttnPlan& p) {
     const int need = hd + 2 * ws;
     static const int depths80[] = {7, 13}, depths64[] = {6, 12};
     const int* d = hd == 80 ? depths80 : depths64;
-    p.nstep = 16 * d[0] >= need ? d[0] : (16 * d[1] >= need ? d[1] : 0);
+    p.bias = ws == BIAS_WS && a.nw == 1;   // the 64 x 64 global blocks
+    p.nstep = p.bias ? hd / 16 : 16 * d[0] >= need ? d[0] : (16 * d[1] >= need ? d[1] : 0);
     if (!p.nstep) return false;
     a.DQ = 16 * p.nstep;
     const size_t G = size_t(B) * a.nw * a.nw * heads;
+    p.tab = p.bias ? G * a.Npad * 2 * ws * sizeof(float) : 0;
     p.qp = G * a.Npad * 2 * a.DQ * sizeof(_Float16);
     p.kp = G * a.Npad * (a.DQ + a.HDP) * sizeof(_Float16);
     p.vp = G * a.Npad * 2 * a.DV * sizeof(_Float16);
     return true;
 }
 
-template <int NSTEP, int HSTEP, int DVT, int WAVES, bool PLAIN>
-int launch_attn(const AttnPlan& p, const _Float16* Qp, const _Float16* Kp, const _Float16* Vp, _Float16* out, unsigned* flag,
-                hipStream_t stream) {
+template <int NSTEP, int HSTEP, int DVT, int WAVES, bool PLAIN, bool BIAS = false>
+int launch_attn(const AttnPlan& p, const _Float16* Qp, const _Float16* Kp, const _Float16* Vp, const void* bias_tab, _Float16* out,
+                unsigned* flag, hipStream_t stream) {
     using C = AttnCfg<NSTEP, HSTEP, DVT, WAVES, PLAIN>;
     constexpr int NT = C::NT, QB = C::QB;
+    constexpr size_t lds = C::LDS_BYTES + (BIAS ? size_t(QB) * BIAS_ST * sizeof(float) : 0);
     static pope_dev_mask done{0};
-    auto kern = sam_attn_kernel<NSTEP, HSTEP, DVT, WAVES, PLAIN>;
-    if (!pope_opt_in_lds(kern, C::LDS_BYTES, done)) return POPE_ERR_LAUNCH;
+    auto kern = sam_attn_kernel<NSTEP, HSTEP, DVT, WAVES, PLAIN, BIAS>;
+    if (!pope_opt_in_lds(kern, lds, done)) return POPE_ERR_LAUNCH;
     const AttnGeom& a = p.geom;
+    if (BIAS && (a.ws != BIAS_WS || a.nw != 1 || (a.Npad / KT) % 2 || !bias_tab)) return POPE_ERR_ARG;
     const long long blocks = (long long)a.B * a.nw * a.nw * a.heads * ((a.Nq + QB - 1) / QB);
     if (blocks <= 0 || blocks > 0x7fffffffll) return POPE_ERR_ARG;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), C::LDS_BYTES, stream, Qp, Kp, Vp, out, a, flag);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, stream, Qp, Kp, Vp, bias_tab, out, a, flag);
     return pope_check_launch();
 }
 
@@ -781,7 +857,7 @@ size_t pope_sam_encoder_workspace(const SamEncParams& q) {
         AttnPlan p;
         const int ws = pass ? g : (q.window > 0 ? q.window : g);
         if (!plan_attention(q.B, g, ws, q.heads, hd, p)) return 0;
-        ops += align256(p.qp) + align256(p.kp) + align256(p.vp) + align256(rows * sizeof(int));
+        ops += align256(p.qp) + align256(p.kp) + align256(p.vp) + align256(p.tab) + align256(rows * sizeof(int));
     }
     const size_t gp = size_t(g) + 2;
     return align256(rows * q.dim * 4) /* x */ + align256(rows * q.dim * 4) /* xn planes */ + align256(big) + ops +
@@ -820,12 +896,13 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
     char* big = take(big_bytes);
     void* att_pl = big;   // attention output (the proj GEMM's operand); fc1's output reuses the buffer
     void* hid_pl = big;
-    struct OpSet { _Float16 *q, *k, *v; int* map; };
+    struct OpSet { _Float16 *q, *k, *v; void* tab; int* map; };
     OpSet ops_w, ops_g;
     for (auto pr : {std::make_pair(&plan_w, &ops_w), std::make_pair(&plan_g, &ops_g)}) {
         pr.second->q = reinterpret_cast<_Float16*>(take(pr.first->qp));
         pr.second->k = reinterpret_cast<_Float16*>(take(pr.first->kp));
         pr.second->v = reinterpret_cast<_Float16*>(take(pr.first->vp));
+        pr.second->tab = take(pr.first->tab);
         pr.second->map = reinterpret_cast<int*>(take(size_t(rows) * sizeof(int)));
     }
     float* t1 = reinterpret_cast<float*>(take(size_t(rows) * oc * 4));
@@ -889,9 +966,11 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
                 return POPE_ERR_LAUNCH;
             const AttnGeom& a = p.geom;
             const int k_row = plain ? a.DQ : a.DQ + a.HDP;
-            hipLaunchKernelGGL(sam_onehot_kernel, dim3(grid_for((long long)a.B * a.nw * a.nw * a.heads * a.Nq)), dim3(256), 0, stream,
-                               os.k, a, k_row);
-            POPE_TRY(pope_check_launch());
+            if (!p.bias) {   // (bias mode: K' has no one-hot columns)
+                hipLaunchKernelGGL(sam_onehot_kernel, dim3(grid_for((long long)a.B * a.nw * a.nw * a.heads * a.Nq)), dim3(256), 0, stream,
+                                   os.k, a, k_row);
+                POPE_TRY(pope_check_launch());
+            }
             hipLaunchKernelGGL(sam_rowmap_kernel, dim3(grid_for(rows)), dim3(256), 0, stream, os.map, a);
             POPE_TRY(pope_check_launch());
         }
@@ -940,10 +1019,15 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
             // both axes of one window batch on one XCD while its Q' rows fit that L2 comfortably (the 28 tasks of a 14 x 14 window: yes;
             // a 64 x 64 global block: no — measured slower, profiles/r04/sam_relpos_lab.txt)
             const int by_xcd = size_t(a.Nq) * a.heads * (plain ? a.DQ : 2 * a.DQ) * 2 <= (1u << 20);
-#define POPE_SAM_RELPOS(HD, MB, PL)                                                                                                       \
-    hipLaunchKernelGGL((sam_attn_relpos_kernel<HD, MB, PL>), rgrid, dim3(256), 0, stream, k.rel_h, k.rel_w, Qp, a, hpg, int(n_tasks), ws_magic, \
-                       by_xcd, flag)
-#define POPE_SAM_RELPOS_MB(HD, PL) do { if (a.ws > 32) POPE_SAM_RELPOS(HD, 2, PL); else POPE_SAM_RELPOS(HD, 1, PL); } while (0)
+#define POPE_SAM_RELPOS(HD, MB, PL, TAB)                                                                                               \
+    hipLaunchKernelGGL((sam_attn_relpos_kernel<HD, MB, PL, TAB>), rgrid, dim3(256), 0, stream, k.rel_h, k.rel_w, Qp, os.tab, a, hpg,       \
+                       int(n_tasks), ws_magic, by_xcd, flag)
+#define POPE_SAM_RELPOS_MB(HD, PL)                               \
+    do {                                                         \
+        if (p.bias) POPE_SAM_RELPOS(HD, 2, PL, true);            \
+        else if (a.ws > 32) POPE_SAM_RELPOS(HD, 2, PL, false);   \
+        else POPE_SAM_RELPOS(HD, 1, PL, false);                  \
+    } while (0)
             if (hd == 80) { if (plain) POPE_SAM_RELPOS_MB(80, true); else POPE_SAM_RELPOS_MB(80, false); }
             else { if (plain) POPE_SAM_RELPOS_MB(64, true); else POPE_SAM_RELPOS_MB(64, false); }
 #undef POPE_SAM_RELPOS_MB
@@ -952,11 +1036,17 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
         }
         _Float16* att = static_cast<_Float16*>(att_pl);
         const bool narrow = a.Nq <= 1024;   // window blocks: 4-wave workgroups; global blocks: 8
-#define POPE_SAM_ATTN_W(NS, HS, DV, W) \
-    (plain ? launch_attn<NS, HS, DV, W, true>(p, Qp, Kp, Vp, att, flag, stream) : launch_attn<NS, HS, DV, W, false>(p, Qp, Kp, Vp, att, flag, stream))
+#define POPE_SAM_ATTN_W(NS, HS, DV, W)                                                            \
+    (plain ? launch_attn<NS, HS, DV, W, true>(p, Qp, Kp, Vp, nullptr, att, flag, stream)          \
+           : launch_attn<NS, HS, DV, W, false>(p, Qp, Kp, Vp, nullptr, att, flag, stream))
 #define POPE_SAM_ATTN(NS, HS, DV) (narrow ? POPE_SAM_ATTN_W(NS, HS, DV, 4) : POPE_SAM_ATTN_W(NS, HS, DV, 8))
-        if (hd == 80) POPE_TRY(p.nstep == 7 ? POPE_SAM_ATTN(7, 5, 3) : POPE_SAM_ATTN(13, 5, 3));
+#define POPE_SAM_ATTN_BIAS(HS, DV)                                                                \
+    (plain ? launch_attn<HS, HS, DV, 8, true, true>(p, Qp, Kp, Vp, os.tab, att, flag, stream)     \
+           : launch_attn<HS, HS, DV, 8, false, true>(p, Qp, Kp, Vp, os.tab, att, flag, stream))
+        if (p.bias) POPE_TRY(hd == 80 ? POPE_SAM_ATTN_BIAS(5, 3) : POPE_SAM_ATTN_BIAS(4, 2));
+        else if (hd == 80) POPE_TRY(p.nstep == 7 ? POPE_SAM_ATTN(7, 5, 3) : POPE_SAM_ATTN(13, 5, 3));
         else POPE_TRY(p.nstep == 6 ? POPE_SAM_ATTN(6, 4, 2) : POPE_SAM_ATTN(12, 4, 2));
+#undef POPE_SAM_ATTN_BIAS
 #undef POPE_SAM_ATTN
 #undef POPE_SAM_ATTN_W
         POPE_TRY(gemm(att_pl, k.proj_wp, k.proj_b, x, nullptr, dim, dim, EPI_BIAS_LS_RES, q.ones, x, 0));
