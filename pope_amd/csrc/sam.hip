@@ -391,7 +391,7 @@ struct AttnCfg {
 // columns instead of 208 (profiles/r04/sam_global_bias_ab.txt).
 constexpr int BIAS_WS = 64, BIAS_ST = BIAS_WS + 1;
 template <int NSTEP, int HSTEP, int DVT, int WAVES, bool PLAIN, bool BIAS>
-__global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void sam_attn_kernel(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp,
+__global__ __launch_bounds__(64 * WAVES, BIAS && PLAIN && WAVES == 4 ? 3 : 8 / WAVES) void sam_attn_kernel(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp,
                                                          const _Float16* __restrict__ Vp, const void* __restrict__ bias_tab,
                                                          _Float16* __restrict__ out_pl, AttnGeom a, unsigned* range_flag) {
     using C = AttnCfg<NSTEP, HSTEP, DVT, WAVES, PLAIN>;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void sam_attn_kernel(const _
     f32x2 l_run = {0.f, 0.f};   // running sum of the 2^10-scaled probabilities, two partial lanes
 
     // bias mode: relh[q][0..64) of the workgroup's queries -> LDS behind the stage, the lane's relw values -> registers
-    float* Bh = smem + C::LDS_BYTES / 4;
+    float* Bh = smem + C::STAGE_BYTES / 4;   // (the epilogue's transposition buffer may overlap it: the table is dead by then)
     float bw[BIAS ? 2 : 1][16];
     if constexpr (BIAS) {
         const BT* tab = static_cast<const BT*>(bias_tab) + ((size_t)grp * a.Npad + q0) * (2 * BIAS_WS);
@@ -813,7 +813,8 @@ int launch_attn(const AttnPlan& p, const _Float16* Qp, const _Float16* Kp, const
                 unsigned* flag, hipStream_t stream) {
     using C = AttnCfg<NSTEP, HSTEP, DVT, WAVES, PLAIN>;
     constexpr int NT = C::NT, QB = C::QB;
-    constexpr size_t lds = C::LDS_BYTES + (BIAS ? size_t(QB) * BIAS_ST * sizeof(float) : 0);
+    constexpr size_t bias_lds = C::STAGE_BYTES + size_t(QB) * BIAS_ST * sizeof(float);
+    constexpr size_t lds = BIAS && bias_lds > C::LDS_BYTES ? bias_lds : C::LDS_BYTES;
     static pope_dev_mask done{0};
     auto kern = sam_attn_kernel<NSTEP, HSTEP, DVT, WAVES, PLAIN, BIAS>;
     if (!pope_opt_in_lds(kern, lds, done)) return POPE_ERR_LAUNCH;
@@ -1040,8 +1041,10 @@ int pope_launch_sam_encoder(const SamEncParams& q, hipStream_t stream) {
     (plain ? launch_attn<NS, HS, DV, W, true>(p, Qp, Kp, Vp, nullptr, att, flag, stream)          \
            : launch_attn<NS, HS, DV, W, false>(p, Qp, Kp, Vp, nullptr, att, flag, stream))
 #define POPE_SAM_ATTN(NS, HS, DV) (narrow ? POPE_SAM_ATTN_W(NS, HS, DV, 4) : POPE_SAM_ATTN_W(NS, HS, DV, 8))
+        // bias mode, plain f16: 4-wave workgroups whose bias table shares the epilogue's LDS (45 KB: three per CU) at <= 168 VGPRs =
+        // three waves per SIMD instead of two: encoder 7.275 -> 7.20 ms per image (profiles/r04/sam_global_bias_ab.txt)
 #define POPE_SAM_ATTN_BIAS(HS, DV)                                                                \
-    (plain ? launch_attn<HS, HS, DV, 8, true, true>(p, Qp, Kp, Vp, os.tab, att, flag, stream)     \
+    (plain ? launch_attn<HS, HS, DV, 4, true, true>(p, Qp, Kp, Vp, os.tab, att, flag, stream)     \
            : launch_attn<HS, HS, DV, 8, false, true>(p, Qp, Kp, Vp, os.tab, att, flag, stream))
         if (p.bias) POPE_TRY(hd == 80 ? POPE_SAM_ATTN_BIAS(5, 3) : POPE_SAM_ATTN_BIAS(4, 2));
         else if (hd == 80) POPE_TRY(p.nstep == 7 ? POPE_SAM_ATTN(7, 5, 3) : POPE_SAM_ATTN(13, 5, 3));
