@@ -200,6 +200,30 @@ def test_fp32_mfma_twin_matches_reference_fixture(hip_lib, golden_dir, name):
     assert torch.equal(got, want) and bool(torch.isfinite(got).all()) and m.overflow_events == 1
 
 
+def test_odd_window_and_odd_grid_match_oracle(hip_lib):
+    """A 7 x 7 window on a 15 x 15 token grid (padded to 21, image_encoder.py:251-254) and a 15 x 15 global block: odd window
+    sides put the w-axis relative-position columns on odd offsets (the 2-byte store path of `sam_attn_relpos_kernel`; the
+    shipped models have 14 and 64) — against the CPU oracle on seeded weights, both precisions, two images."""
+    from oracle import sam_encoder_ref
+    from pope_amd import synth
+    from pope_amd.sam_encoder import ImageEncoderViT
+    dim, depth, heads, img, window, gidx = 256, 2, 4, 240, 7, (1,)
+    m = ImageEncoderViT(depth=depth, embed_dim=dim, img_size=img, mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+                        num_heads=heads, patch_size=16, qkv_bias=True, use_rel_pos=True, global_attn_indexes=list(gidx),
+                        window_size=window, out_chans=256)
+    sd = synth.synthetic_sam_encoder_state_dict(seed=6, dim=dim, depth=depth, heads=heads, grid=img // 16, window=window, global_idx=gidx)
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().cuda()
+    x = synth.synthetic_images(2, img, img, seed=9)
+    with torch.no_grad():
+        want = sam_encoder_ref.forward(sd, x, heads, window, gidx)
+    for prec, tol in (("f16x3", ATOL_OUT), ("f16", ATOL_F16)):
+        m.precision = prec
+        err = float((m(x.cuda()).cpu() - want).abs().max())
+        print(f"odd window [{prec}]: max |out - oracle| = {err:.2e}")
+        assert err <= tol and m.overflow_events == 0
+
+
 def test_default_norm_layer_eps_1e5(hip_lib):
     """ImageEncoderViT() with the reference constructor's default norm_layer (nn.LayerNorm: eps 1e-5, image_encoder.py:27)
     runs with that eps in the blocks and 1e-6 in the neck's LayerNorm2d (common.py:28) — against the oracle."""
