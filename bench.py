@@ -626,7 +626,7 @@ def config5_leg(device, iters=3):
                               window_size=14, out_chans=256)
         enc.load_state_dict(synth.synthetic_sam_encoder_state_dict(seed=0, global_idx=gidx), strict=True)
         enc = enc.eval().to(device)
-        SB = 12   # images per launch sequence: 192 row tiles of 256 -> 3.75 / 11.25 / 15 rounds of the 256 x 256 GEMM tiles (8 images: 2.5 / 7.5 / 10)
+        SB = 16   # images per launch sequence: 256 row tiles of 256 -> 5 / 15 / 20 whole rounds of the 256 x 256 GEMM tiles (12 images: 3.75 / 11.25 / 15; 8: 2.5 / 7.5 / 10)
         enc.max_batch = SB
         x = synth.synthetic_images(SB, 1024, 1024, seed=3, device=device)
         n, dim, hd, heads = 4096, 1280, 80, 16
