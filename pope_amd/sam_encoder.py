@@ -134,7 +134,7 @@ class ImageEncoderViT(nn.Module):
         self.precision = "f16x3"
         self.on_overflow = "rerun_f32"  # f16x3 / f16 range guard: "rerun_f32" (warn, run the call again on the fp32 MFMA) | "raise"
         self.overflow_events = 0
-        self.max_batch = 8             # images per launch sequence (32-bit offsets of the GEMMs: 4096 x 5120 x 4 B x B)
+        self.max_batch = 16            # images per launch sequence: 256 row tiles = whole rounds of the 256 x 256 GEMM tiles at ViT-H (32-bit offsets of the GEMMs cap it: 4096 x 5120 x 4 B x B < 4 GiB)
         self._wcache = {}
         self._src = None
         self._ws = None
