@@ -171,7 +171,12 @@ __global__ __launch_bounds__(PL_THREADS) void gemm_plain256_kernel(const GemmPar
         // this wave's pieces of stage kt have landed (the younger K-step's 4 + NIW instructions may still be in flight) ...
         if (NST == 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | (4 + NIW));
         else __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();   // ... and everyone's; every wave has left the stage of K-step kt - 1, which the next DMA overwrites
+        // ... and everyone's; every wave has left the stage of K-step kt - 1, which the next DMA overwrites.  (__syncthreads() is a
+        // fence: the compiler drains every LDS-direct load in front of it — s_waitcnt vmcnt(0) in the ISA whatever the line above
+        // says — so the third stage of the narrow tiles never has a second K-step in flight.  With a bare s_barrier it has: parity
+        // green, LoFTR leg 1 048 / 1 055 against 1 054 / 1 060 pairs/s — no change, the K-step does not wait for its operands:
+        // profiles/r04/lds_dma_lab.txt.)
+        __syncthreads();
         if (kt + NST - 1 < nk) stage_kstep((kt + NST - 1) % NST, kt + NST - 1);
         const _Float16* S = lds + (kt % NST) * STAGE;
         // A K-step = 2 halves x SUB sub-tiles x 4 row blocks = U units of one activation fragment and four MFMAs (against the
