@@ -30,6 +30,10 @@ __device__ __forceinline__ f32x2 gelu_pair(f32x2 x) {   // gemm_plain.hip: pl_ge
     return __builtin_elementwise_fma(relu, __builtin_elementwise_fma(q, f32x2{-2.f, -2.f}, f32x2{1.f, 1.f}), x * q);
 }
 
+#define GELU_PAIR(v) gelu_pair(v)
+#ifndef PER_GAP
+#define PER_GAP 2
+#endif
 constexpr int NK = 12;   // K = 384
 
 template <int MODE>
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256) void overlap(const _Float16* __restrict__ A, c
     float checksum = 0.f;
     // epilogue of one accumulator register (4 values of one row block / column block): GELU + f16 store from the MFMA layout
     auto epi_reg = [&](f32x4 v, int tile, int idx) {
-        const f32x2 g0 = gelu_pair(f32x2{v[0], v[1]}), g1 = gelu_pair(f32x2{v[2], v[3]});
+        const f32x2 g0 = GELU_PAIR((f32x2{v[0], v[1]})), g1 = GELU_PAIR((f32x2{v[2], v[3]}));
         const f16x4 h = __builtin_convertvector(f32x4{g0[0], g0[1], g1[0], g1[1]} * 8.0f, f16x4);
         *reinterpret_cast<f16x4*>(out + (((size_t)tile * 256 + tid) * 32 + idx) * 4) = h;
     };
@@ -112,7 +116,8 @@ __global__ __launch_bounds__(256) void overlap(const _Float16* __restrict__ A, c
                     const int u = kt * 8 + r;   // the register's conversion + store behind its second pair
                     if (u < 64) {
                         f32x4& v = prev[(u >> 1) >> 2][(u >> 1) & 3];
-                        const f32x2 gp = gelu_pair((u & 1) ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]});
+                        const f32x2 gin = (u & 1) ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]};
+                        const f32x2 gp = GELU_PAIR(gin);
                         if (u & 1) {
                             const f16x4 h4 = __builtin_convertvector(f32x4{v[0], v[1], gp[0], gp[1]} * 8.0f, f16x4);
                             *reinterpret_cast<f16x4*>(out + (((size_t)(prev_tile < 0 ? tile : prev_tile) * 256 + tid) * 32 + (u >> 1)) * 4) = h4;
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256) void overlap(const _Float16* __restrict__ A, c
 #pragma unroll
                         for (int i = 0; i < 12; ++i) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, PER_GAP, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);   // the slice stays in its unit
