@@ -554,14 +554,17 @@ __global__ __launch_bounds__(64 * WAVES, BIAS && PLAIN && WAVES == 4 ? 3 : 8 / W
         }
         m_run = m_new;
         const float mshift = m_new - 10.0f;
-        f32x2 ls = {0.f, 0.f};
+        float ls0 = 0.f, ls1 = 0.f;   // two plain sums (a v_pk_add_f32 beside the other wave's MFMAs costs more than two v_add_f32: attention_f16x3.hip)
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
             s[i] = __builtin_amdgcn_exp2f(s[i] - mshift);
             s[i + 1] = __builtin_amdgcn_exp2f(s[i + 1] - mshift);
-            ls += f32x2{s[i], s[i + 1]};
+            ls0 += s[i];
+            asm volatile("" : "+v"(ls0));
+            ls1 += s[i + 1];
+            asm volatile("" : "+v"(ls1));
         }
-        l_run += ls;
+        l_run += f32x2{ls0, ls1};
 
         // ---- O^T += V^T.P^T: score registers 8 s .. 8 s + 7 are the B fragment of k-step s
 #pragma unroll
